@@ -1,0 +1,154 @@
+/*
+ * ptrt.h -- C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference renderer has no FFI layer; its operator interface is the Rust struct
+ * `Renderer` (src/renderer.rs:13-29) and the bind group it feeds to the compute shader
+ * (shaders/compute.wgsl:72-81).  Each entry point below names the reference interface it
+ * replaces.  All byte layouts are the reference's own #[repr(C)] Pod structs, passed as
+ * `const void*` so a Rust caller hands over `bytemuck::bytes_of(..)` unchanged:
+ *
+ *   camera   64 B    CameraBuffer       src/scene/camera.rs:73-84
+ *   settings 16 B    Settings           src/renderer.rs:604-611
+ *   spheres  8208 B  SphereDataBuffer   src/scene/sphere.rs:105-111
+ *   triangle 112 B   TriangleBuffer     src/model.rs:51-68
+ *   node     32 B    Node               src/scene/bvh.rs:7-14
+ *
+ * Conventions: every function returns PT_OK (0) or a negative pt_status; nothing throws,
+ * aborts or prints.  pt_last_error() gives the message of the last failure on that
+ * context (or, with NULL, of the last failed pt_create on this thread).  A context is
+ * bound to one GPU and must be used from one host thread at a time.  Calls that launch
+ * work are asynchronous on the context's stream unless they return data to the host.
+ */
+#ifndef PTRT_H
+#define PTRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, malformed BVH ...) */
+    PT_ERR_HIP = -2,       /* a HIP runtime call failed; message carries hipGetErrorString */
+    PT_ERR_NOMEM = -3,     /* host or device allocation failed */
+    PT_ERR_STATE = -4,     /* call not valid in the context's current state */
+    PT_ERR_LIMIT = -5      /* input exceeds a documented limit */
+} pt_status;
+
+/* pt_set_flags bits */
+#define PT_FLAG_REFERENCE_DISPATCH 1u /* render only floor(w/16)*16 x floor(h/16)*16 pixels, as
+                                         dispatch_workgroups(w/16, h/16, 1) does (renderer.rs:565-569) */
+#define PT_FLAG_AOV 2u                /* record the primary hit of each pixel's first sample */
+#define PT_FLAG_DETAILED_STATS 4u     /* count node steps / triangle tests too (slower kernel) */
+
+/* Primitive ids reported by pt_read_aov / pt_trace_rays */
+#define PT_PRIM_NONE 0xFFFFFFFFu      /* miss */
+#define PT_PRIM_SPHERE 0x80000000u    /* sphere i is PT_PRIM_SPHERE | i; triangles are their index */
+
+typedef struct pt_stats_t {
+    uint64_t rays;          /* hitScene calls (compute.wgsl:138): the unit of Mrays/s */
+    uint64_t paths;         /* rayColor calls */
+    uint64_t interior;      /* interior-node steps          (PT_FLAG_DETAILED_STATS only) */
+    uint64_t tri_tests;     /* hitTriangle calls            (PT_FLAG_DETAILED_STATS only) */
+    uint64_t tri_accept;    /* accepted triangle hits       (PT_FLAG_DETAILED_STATS only) */
+    uint64_t sphere_tests;  /* hitSphere calls              (PT_FLAG_DETAILED_STATS only) */
+    uint64_t sky_lookups;   /* getBackgroundColor calls     (PT_FLAG_DETAILED_STATS only) */
+    uint64_t bounces;       /* material switch executions   (PT_FLAG_DETAILED_STATS only) */
+    uint64_t frames;        /* dispatch-equivalents accumulated since the last pt_reset */
+    uint64_t bvh_depth;     /* deepest leaf of the uploaded BVH = traversal stack bound */
+} pt_stats_t;
+
+/* ---- lifetime: Renderer::new / drop (src/renderer.rs:32-37) ------------------------ */
+/* Creates a renderer for a width x height image on HIP device `device`.  The reference
+ * hard-codes 1920x1080 output textures (renderer.rs:157-176); here it is a parameter. */
+int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out);
+void pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(const pt_ctx *ctx);
+
+/* Launch stream (hipStream_t); NULL = the default stream.  No counterpart: wgpu owns its queue. */
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+int pt_set_flags(pt_ctx *ctx, uint32_t flags);
+
+/* ---- static scene: the create_buffer_init uploads of Renderer::new (renderer.rs:220-241)
+ * tris: n_tris x 112 B, nodes: n_nodes x 32 B, tri_idx: n_idx x u32 (bindings 3, 5, 4 of
+ * compute.wgsl:75-77).  Copied; the caller's memory is not referenced afterwards.  The BVH is
+ * validated (child/leaf ranges in bounds, children stored after their parent) so that a
+ * malformed tree is rejected instead of hanging the GPU.  n_nodes == 0 clears the mesh. */
+int pt_set_mesh(pt_ctx *ctx, const void *tris, uint32_t n_tris, const void *nodes, uint32_t n_nodes,
+                const uint32_t *tri_idx, uint32_t n_idx);
+
+/* Sky cube map, binding 7 (compute.wgsl:79): 6 faces (+X,-X,+Y,-Y,+Z,-Z) of size x size RGBA32F
+ * texels, row-major, as produced by CubeTexture::from_equirectangular_hdri (texture.rs:172-270). */
+int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size);
+/* Same, but runs the equirectangular->cube kernel (shaders/equirectangular.wgsl:12-81) on the GPU
+ * from a decoded w x h RGBA32F panorama (texture.rs:179-188). */
+int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size);
+/* Copies the current cube map back to the host (6*size*size*4 floats). */
+int pt_read_sky_cube(pt_ctx *ctx, float *out);
+
+/* ---- per-frame uniforms: Renderer::update_buffers (renderer.rs:518-548) ------------ */
+int pt_set_camera(pt_ctx *ctx, const void *camera64);
+int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208);
+int pt_set_settings(pt_ctx *ctx, const void *settings16);
+
+/* ---- the hot path: Renderer::render's compute pass (renderer.rs:562-570) ----------- */
+/* One dispatch of compute.wgsl::main with the `time` uniform (binding 6) given explicitly
+ * (the reference derives it from the wall clock, renderer.rs:518-522).  The per-pixel mean
+ * over settings.spp samples is ADDED to the fp32 accumulation buffer and the frame count
+ * goes up by one. */
+int pt_render(pt_ctx *ctx, uint32_t time);
+/* n_frames dispatch-equivalents in one launch: frame i uses time0 + i*stride.  Bit-identical
+ * to n_frames pt_render calls; lanes start their next frame as soon as their path ends. */
+int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames);
+/* ProgressiveRendering::reset_ready_samples (renderer.rs:635-637): clears the accumulation. */
+int pt_reset(pt_ctx *ctx);
+int pt_sync(pt_ctx *ctx);
+
+/* ---- results ----------------------------------------------------------------------- */
+/* Raw accumulation buffer: width*height RGBA32F sums; A holds the frame count. */
+int pt_read_sum_rgba32f(pt_ctx *ctx, float *out);
+/* sum / frames: the image copy.wgsl:27-37 converges to, without its 8-bit quantisation. */
+int pt_read_mean_rgba32f(pt_ctx *ctx, float *out);
+/* Mean clamped to [0,1] and quantised like an rgba8unorm store (compute.wgsl:72,127). */
+int pt_read_rgba8(pt_ctx *ctx, uint8_t *out);
+/* Primary-hit primitive id and t per pixel (needs PT_FLAG_AOV during rendering). */
+int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t);
+int pt_stats(pt_ctx *ctx, pt_stats_t *out);
+/* Device address of the accumulation buffer (for collectives on it), and a way to make the
+ * renderer accumulate into caller-owned device memory of width*height*16 bytes instead. */
+void *pt_accum_device_ptr(pt_ctx *ctx);
+int pt_bind_accum(pt_ctx *ctx, void *device_ptr);
+
+/* Closest hit of n explicit rays through the same hitScene code (compute.wgsl:214-302).
+ * origins/dirs: n x 3 floats.  Outputs (each may be NULL): prim n x u32, t n x f32,
+ * p n x 3, normal n x 3, front n x u32. */
+int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim,
+                  float *t, float *p, float *normal, uint32_t *front);
+
+/* ---- host-side scene construction (no GPU needed) ---------------------------------- */
+/* Bvh::from_triangles (src/scene/bvh.rs:34-66): same nodes and same index permutation.
+ * nodes_out holds 2*n_tris-1 records of 32 B, idx_out n_tris u32.  Returns nodes used,
+ * 0 for an empty mesh, negative pt_status on bad arguments. */
+int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out);
+/* Plane::triangles (src/scene/plane.rs:16-41): writes two 112-byte records. */
+int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3],
+                       uint32_t material, void *tris_out);
+/* SphereDataBuffer::from(&Vec<Sphere>) (src/scene/sphere.rs:113-130): n spheres given as
+ * n x {center[3], radius, albedo[3], material as f32}; clamps to 256. */
+int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data8208_out);
+/* Model::from_obj (src/model.rs:111-213) for the v / vn / f subset: first call with
+ * tris_out == NULL to get the triangle count in *n_tris, then with a buffer of that many
+ * 112-byte records.  Faces are fan-triangulated; vertices without `vn` get area-weighted
+ * smooth normals (the reference would panic on a file without normals). */
+int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris);
+/* Message of the last failed host-side helper on this thread. */
+const char *pt_host_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRT_H */

@@ -1,0 +1,365 @@
+"""Host-side binding of libptrt.so (the C ABI declared in include/ptrt.h).
+
+This mirrors the reference's host objects so that tests read like its own code would:
+``Scene`` (src/scene/mod.rs:26-43), ``Camera`` (src/scene/camera.rs:11-44),
+``Sphere``/``Material`` (src/scene/sphere.rs, src/scene/mod.rs:18-24), ``Plane``
+(src/scene/plane.rs) and ``Renderer`` with ``render`` / ``reset_ready_samples``
+(src/renderer.rs:13-37, 551-557, 635-637).  All compute happens in the HIP library; if it
+cannot be loaded every entry point raises -- there is no CPU fallback.
+
+The directory name contains a hyphen, so import it through ``load()`` in ``_pkgload.py`` at the
+repository root (or ``importlib``), under the module name ``path_tracer_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from enum import IntEnum
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptrt.so")
+
+PT_FLAG_REFERENCE_DISPATCH = 1
+PT_FLAG_AOV = 2
+PT_FLAG_DETAILED_STATS = 4
+PRIM_NONE = 0xFFFFFFFF
+PRIM_SPHERE = 0x80000000
+
+# numpy views of the reference's Pod structs
+TRIANGLE_DTYPE = np.dtype(
+    [("a", "<f4", 3), ("_p0", "<f4"), ("b", "<f4", 3), ("_p1", "<f4"), ("c", "<f4", 3), ("_p2", "<f4"),
+     ("na", "<f4", 3), ("_p3", "<f4"), ("nb", "<f4", 3), ("_p4", "<f4"), ("nc", "<f4", 3), ("_p5", "<f4"),
+     ("albedo", "<f4", 3), ("material", "<u4")])
+NODE_DTYPE = np.dtype([("min", "<f4", 3), ("left", "<u4"), ("max", "<f4", 3), ("count", "<u4")])
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("albedo", "<f4", 3), ("material", "<f4")])
+SPHERE_DATA_DTYPE = np.dtype([("count", "<u4"), ("_pad", "<u4", 3), ("spheres", SPHERE_DTYPE, 256)])
+CAMERA_DTYPE = np.dtype([("origin", "<f4", 3), ("focal_length", "<f4"), ("forward", "<f4", 3), ("vfov", "<f4"),
+                         ("right", "<f4", 3), ("_p1", "<u4"), ("up", "<f4", 3), ("_p2", "<u4")])
+SETTINGS_DTYPE = np.dtype([("spp", "<u4"), ("depth", "<u4"), ("t_min", "<f4"), ("t_max", "<f4")])
+assert TRIANGLE_DTYPE.itemsize == 112 and NODE_DTYPE.itemsize == 32 and SPHERE_DTYPE.itemsize == 32
+assert SPHERE_DATA_DTYPE.itemsize == 8208 and CAMERA_DTYPE.itemsize == 64 and SETTINGS_DTYPE.itemsize == 16
+
+
+class PtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"ptrt error {code}: {message}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "interior", "tri_tests", "tri_accept", "sphere_tests",
+                                          "sky_lookups", "bounces", "frames", "bvh_depth")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib = None
+
+# every symbol include/ptrt.h declares: (name, restype, argtypes)
+_VP, _U32, _I = C.c_void_p, C.c_uint32, C.c_int
+ABI = [
+    ("pt_create", _I, [_I, _U32, _U32, C.POINTER(_VP)]),
+    ("pt_destroy", None, [_VP]),
+    ("pt_last_error", C.c_char_p, [_VP]),
+    ("pt_set_stream", _I, [_VP, _VP]),
+    ("pt_set_flags", _I, [_VP, _U32]),
+    ("pt_set_mesh", _I, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
+    ("pt_set_sky_cube", _I, [_VP, _VP, _U32]),
+    ("pt_set_sky_equirect", _I, [_VP, _VP, _U32, _U32, _U32]),
+    ("pt_read_sky_cube", _I, [_VP, _VP]),
+    ("pt_set_camera", _I, [_VP, _VP]),
+    ("pt_set_spheres", _I, [_VP, _VP]),
+    ("pt_set_settings", _I, [_VP, _VP]),
+    ("pt_render", _I, [_VP, _U32]),
+    ("pt_render_frames", _I, [_VP, _U32, _U32, _U32]),
+    ("pt_reset", _I, [_VP]),
+    ("pt_sync", _I, [_VP]),
+    ("pt_read_sum_rgba32f", _I, [_VP, _VP]),
+    ("pt_read_mean_rgba32f", _I, [_VP, _VP]),
+    ("pt_read_rgba8", _I, [_VP, _VP]),
+    ("pt_read_aov", _I, [_VP, _VP, _VP]),
+    ("pt_stats", _I, [_VP, C.POINTER(Stats)]),
+    ("pt_accum_device_ptr", _VP, [_VP]),
+    ("pt_bind_accum", _I, [_VP, _VP]),
+    ("pt_trace_rays", _I, [_VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP]),
+    ("pt_bvh_build", C.c_int64, [_VP, _U32, _VP, _VP]),
+    ("pt_plane_triangles", _I, [_VP, _VP, _VP, _VP, _U32, _VP]),
+    ("pt_pack_spheres", _I, [_VP, _U32, _VP]),
+    ("pt_obj_load", _I, [C.c_char_p, _VP, _U32, C.POINTER(_U32)]),
+    ("pt_host_error", C.c_char_p, []),
+]
+
+
+def lib() -> C.CDLL:
+    """Loads libptrt.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtError(-4, f"{LIB_PATH} not built; run `make -C path-tracer_amd/csrc` (there is no CPU fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _host_check(rc: int):
+    if rc < 0:
+        raise PtError(int(rc), lib().pt_host_error().decode())
+
+
+class Material(IntEnum):  # src/scene/mod.rs:18-24
+    Diffuse = 0
+    Metal = 1
+    Dielectric = 2
+    Gizmo = 3
+
+
+@dataclass
+class Sphere:  # SphereDescriptor, src/scene/sphere.rs:10-15
+    center: Sequence[float]
+    radius: float
+    albedo: Sequence[float]
+    material: Material = Material.Diffuse
+
+
+@dataclass
+class Plane:  # src/scene/plane.rs:7-13
+    q: Sequence[float]
+    u: Sequence[float]
+    v: Sequence[float]
+    albedo: Sequence[float] = (1.0, 1.0, 1.0)
+    material: Material = Material.Diffuse
+
+    def triangles(self) -> np.ndarray:
+        out = np.zeros(2, TRIANGLE_DTYPE)
+        f = lambda s: np.ascontiguousarray(s, np.float32)
+        q, u, v, al = f(self.q), f(self.u), f(self.v), f(self.albedo)
+        _host_check(lib().pt_plane_triangles(_ptr(q), _ptr(u), _ptr(v), _ptr(al), int(self.material), _ptr(out)))
+        return out
+
+
+@dataclass
+class Camera:  # src/scene/camera.rs:11-44
+    origin: Sequence[float] = (1.0, 1.0, 4.7)
+    forward: Sequence[float] = (0.0, 0.0, -1.0)
+    right: Sequence[float] = (1.0, 0.0, 0.0)
+    up: Sequence[float] = (0.0, 1.0, 0.0)
+    focal_length: float = 1.0
+    vfov: float = 75.0
+
+    @staticmethod
+    def from_yaw_pitch(origin, yaw_deg=-90.0, pitch_deg=0.0, focal_length=1.0, vfov=75.0) -> "Camera":
+        """Basis as CameraController::update_camera builds it (camera.rs:214-226), in f32."""
+        f32 = np.float32
+        yaw, pitch = np.deg2rad(f32(yaw_deg), dtype=f32), np.deg2rad(f32(pitch_deg), dtype=f32)
+        fwd = np.array([np.cos(yaw) * np.cos(pitch), np.sin(pitch), np.sin(yaw) * np.cos(pitch)], f32)
+        norm = lambda v: (v * (f32(1.0) / np.sqrt(np.sum(v * v, dtype=f32), dtype=f32))).astype(f32)
+        fwd = norm(fwd)
+        right = norm(np.cross(fwd, np.array([0, 1, 0], f32)).astype(f32))
+        up = norm(np.cross(right, fwd).astype(f32))
+        return Camera(tuple(origin), tuple(fwd), tuple(right), tuple(up), focal_length, vfov)
+
+    def buffer(self) -> np.ndarray:  # CameraBuffer::from, camera.rs:86-99
+        b = np.zeros(1, CAMERA_DTYPE)
+        b["origin"], b["forward"], b["right"], b["up"] = self.origin, self.forward, self.right, self.up
+        b["focal_length"], b["vfov"] = self.focal_length, self.vfov
+        return b
+
+
+@dataclass
+class Settings:  # src/renderer.rs:604-611, defaults :411-416
+    samples_per_pixel: int = 1
+    depth: int = 32
+    t_min: float = 0.0001
+    t_max: float = 1000.0
+
+    def buffer(self) -> np.ndarray:
+        b = np.zeros(1, SETTINGS_DTYPE)
+        b["spp"], b["depth"], b["t_min"], b["t_max"] = self.samples_per_pixel, self.depth, self.t_min, self.t_max
+        return b
+
+
+def pack_spheres(spheres: Sequence[Sphere]) -> np.ndarray:
+    """SphereDataBuffer::from(&Vec<Sphere>), src/scene/sphere.rs:113-130."""
+    raw = np.zeros(len(spheres), SPHERE_DTYPE)
+    for i, s in enumerate(spheres):
+        raw[i] = (tuple(s.center), s.radius, tuple(s.albedo), float(int(s.material)))
+    out = np.zeros(1, SPHERE_DATA_DTYPE)
+    _host_check(lib().pt_pack_spheres(_ptr(raw), len(spheres), _ptr(out)))
+    return out
+
+
+def bvh_build(triangles: np.ndarray):
+    """Bvh::from_triangles, src/scene/bvh.rs:34-66 -> (nodes, triangle_indices)."""
+    triangles = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+    n = len(triangles)
+    if n == 0:
+        return np.zeros(0, NODE_DTYPE), np.zeros(0, np.uint32)
+    nodes = np.zeros(2 * n - 1, NODE_DTYPE)
+    idx = np.zeros(n, np.uint32)
+    used = lib().pt_bvh_build(_ptr(triangles), n, _ptr(nodes), _ptr(idx))
+    _host_check(used)
+    return nodes[:used].copy(), idx
+
+
+def load_obj(path: str) -> np.ndarray:
+    """Model::from_obj, src/model.rs:111-213 (v / vn / f subset) -> triangle records."""
+    n = C.c_uint32(0)
+    _host_check(lib().pt_obj_load(path.encode(), None, 0, C.byref(n)))
+    out = np.zeros(n.value, TRIANGLE_DTYPE)
+    if n.value:
+        _host_check(lib().pt_obj_load(path.encode(), _ptr(out), n.value, C.byref(n)))
+    return out
+
+
+@dataclass
+class Scene:
+    """Scene::new builds the BVH from the triangle list (src/scene/mod.rs:35-43)."""
+    spheres: List[Sphere]
+    triangles: np.ndarray
+    camera: Camera
+    nodes: np.ndarray = field(init=False)
+    triangle_indices: np.ndarray = field(init=False)
+
+    def __post_init__(self):
+        self.triangles = np.ascontiguousarray(self.triangles, TRIANGLE_DTYPE)
+        self.nodes, self.triangle_indices = bvh_build(self.triangles)
+
+
+class Renderer:
+    """Renderer::new(device, queue, surface_config, scene) / render / reset_ready_samples."""
+
+    def __init__(self, scene: Scene, width: int, height: int, device: int = 0, settings: Optional[Settings] = None,
+                 flags: int = 0, stream: int = 0):
+        self._ctx = C.c_void_p()
+        self._l = lib()
+        rc = self._l.pt_create(device, width, height, C.byref(self._ctx))
+        if rc != 0:
+            raise PtError(rc, self._l.pt_last_error(None).decode())
+        self.width, self.height = width, height
+        self.settings = settings or Settings()
+        if stream:
+            self._ck(self._l.pt_set_stream(self._ctx, C.c_void_p(stream)))
+        if flags:
+            self.set_flags(flags)
+        self.set_mesh(scene.triangles, scene.nodes, scene.triangle_indices)
+        self.update_scene(scene)
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise PtError(rc, self._l.pt_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            self._l.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_flags(self, flags: int):
+        self._ck(self._l.pt_set_flags(self._ctx, flags))
+
+    def set_mesh(self, triangles: np.ndarray, nodes: np.ndarray, tri_idx: np.ndarray):
+        triangles = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+        nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+        tri_idx = np.ascontiguousarray(tri_idx, np.uint32)
+        self._ck(self._l.pt_set_mesh(self._ctx, _ptr(triangles), len(triangles), _ptr(nodes), len(nodes),
+                                     _ptr(tri_idx), len(tri_idx)))
+
+    def set_sky_cube(self, faces: np.ndarray):
+        faces = np.ascontiguousarray(faces, np.float32)
+        assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 4
+        self._ck(self._l.pt_set_sky_cube(self._ctx, _ptr(faces), faces.shape[1]))
+
+    def set_sky_equirect(self, pano: np.ndarray, cube_size: int):
+        pano = np.ascontiguousarray(pano, np.float32)
+        assert pano.ndim == 3 and pano.shape[2] == 4
+        self._ck(self._l.pt_set_sky_equirect(self._ctx, _ptr(pano), pano.shape[1], pano.shape[0], cube_size))
+        self._sky_size = cube_size
+
+    def read_sky_cube(self, size: int) -> np.ndarray:
+        out = np.zeros((6, size, size, 4), np.float32)
+        self._ck(self._l.pt_read_sky_cube(self._ctx, _ptr(out)))
+        return out
+
+    def update_scene(self, scene: Scene):
+        """The per-frame uniform uploads of Renderer::update_buffers (renderer.rs:524-548)."""
+        cam, sph, st = scene.camera.buffer(), pack_spheres(scene.spheres), self.settings.buffer()
+        self._ck(self._l.pt_set_camera(self._ctx, _ptr(cam)))
+        self._ck(self._l.pt_set_spheres(self._ctx, _ptr(sph)))
+        self._ck(self._l.pt_set_settings(self._ctx, _ptr(st)))
+
+    def set_settings(self, settings: Settings):
+        self.settings = settings
+        st = settings.buffer()
+        self._ck(self._l.pt_set_settings(self._ctx, _ptr(st)))
+
+    def render(self, time: int):
+        self._ck(self._l.pt_render(self._ctx, time & 0xFFFFFFFF))
+
+    def render_frames(self, time0: int, stride: int, n_frames: int):
+        self._ck(self._l.pt_render_frames(self._ctx, time0 & 0xFFFFFFFF, stride, n_frames))
+
+    def reset_ready_samples(self):
+        self._ck(self._l.pt_reset(self._ctx))
+
+    def sync(self):
+        self._ck(self._l.pt_sync(self._ctx))
+
+    def read_sum(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(self._l.pt_read_sum_rgba32f(self._ctx, _ptr(out)))
+        return out
+
+    def read_mean(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(self._l.pt_read_mean_rgba32f(self._ctx, _ptr(out)))
+        return out
+
+    def read_rgba8(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._ck(self._l.pt_read_rgba8(self._ctx, _ptr(out)))
+        return out
+
+    def read_aov(self):
+        prim = np.zeros((self.height, self.width), np.uint32)
+        t = np.zeros((self.height, self.width), np.float32)
+        self._ck(self._l.pt_read_aov(self._ctx, _ptr(prim), _ptr(t)))
+        return prim, t
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._ck(self._l.pt_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def accum_device_ptr(self) -> int:
+        return int(self._l.pt_accum_device_ptr(self._ctx) or 0)
+
+    def bind_accum(self, device_ptr: int):
+        self._ck(self._l.pt_bind_accum(self._ctx, C.c_void_p(device_ptr)))
+
+    def trace_rays(self, origins: np.ndarray, dirs: np.ndarray):
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(origins)
+        prim, t = np.zeros(n, np.uint32), np.zeros(n, np.float32)
+        p, nrm, front = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.uint32)
+        self._ck(self._l.pt_trace_rays(self._ctx, _ptr(origins), _ptr(dirs), n, _ptr(prim), _ptr(t), _ptr(p),
+                                       _ptr(nrm), _ptr(front)))
+        return prim, t, p, nrm, front

@@ -1,0 +1,590 @@
+// pt_api.hip -- implementation of the C ABI in include/ptrt.h: context, uploads, launches.
+//
+// Device data layout (all hipMalloc, lives for the context):
+//   accum     width*height float4   running RGB sums, .w = frame count
+//   spheres   2 float4 per sphere   {center, radius} {albedo, material}
+//   nodes     2 float4 per node     {min, token} {max, count}; the array is stored one node
+//                                   late so that every sibling pair (odd, even index) is one
+//                                   64-byte aligned block
+//   node_meta uint2 per node        (first, count), read only for leaves with > 7 triangles
+//   tri_pos   3 float4 per slot     {a, original index} {b-a} {c-a}, slot = position in the
+//                                   BVH's index permutation, so a leaf's triangles are contiguous
+//   tri_nrm   3 float4 per slot     vertex normals, touched once per closest hit
+//   sky       6*size*size float4    cube faces +X,-X,+Y,-Y,+Z,-Z
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrt.h"
+#include "pt_kernels.h"
+
+struct pt_ctx {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    uint32_t flags = 0;
+    std::string err;
+
+    PtCamera camera{};
+    PtSettings settings{1, 32, 0.0001f, 1000.0f};  // Renderer::new defaults, renderer.rs:411-416
+    bool have_camera = false;
+
+    float4 *accum_owned = nullptr, *accum = nullptr;
+    uint32_t *aov_prim = nullptr;
+    float *aov_t = nullptr;
+    unsigned long long *counters = nullptr;
+
+    float4 *spheres = nullptr;
+    uint32_t n_spheres = 0;
+
+    float4 *nodes_alloc = nullptr;
+    uint2 *node_meta = nullptr;
+    float4 *tri_pos = nullptr, *tri_nrm = nullptr;
+    uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0;
+
+    float4 *sky = nullptr;
+    uint32_t sky_size = 0;
+
+    uint32_t *gstack = nullptr;
+    size_t gstack_bytes = 0;
+    uint32_t gstack_cap = 0;
+
+    void *scratch = nullptr;  // read-back staging for resolve
+    size_t scratch_bytes = 0;
+
+    uint64_t frames = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(pt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define PT_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                        \
+    } while (0)
+
+#define PT_ENTER(ctx)                                                    \
+    do {                                                                 \
+        if (!(ctx)) return fail(nullptr, PT_ERR_INVALID, "null context"); \
+        PT_HIP(ctx, hipSetDevice((ctx)->device));                        \
+    } while (0)
+
+template <typename T>
+int dev_alloc(pt_ctx *ctx, T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) return PT_OK;
+    PT_HIP(ctx, hipMalloc((void **)p, count * sizeof(T)));
+    return PT_OK;
+}
+template <typename T>
+void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int ensure_scratch(pt_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes) return PT_OK;
+    dev_free(ctx->scratch);
+    ctx->scratch_bytes = 0;
+    PT_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return PT_OK;
+}
+
+void free_mesh(pt_ctx *ctx)
+{
+    dev_free(ctx->nodes_alloc);
+    dev_free(ctx->node_meta);
+    dev_free(ctx->tri_pos);
+    dev_free(ctx->tri_nrm);
+    ctx->n_nodes = 0;
+    ctx->root_token = 0;
+    ctx->bvh_depth = 0;
+}
+
+PtDeviceScene device_scene(const pt_ctx *ctx)
+{
+    PtDeviceScene sc{};
+    sc.spheres = ctx->spheres;
+    sc.n_spheres = ctx->n_spheres;
+    sc.nodes = ctx->nodes_alloc ? ctx->nodes_alloc + 2 : nullptr;  // +1 node: see layout note above
+    sc.node_meta = ctx->node_meta;
+    sc.n_nodes = ctx->n_nodes;
+    sc.root_token = ctx->root_token;
+    sc.tri_pos = ctx->tri_pos;
+    sc.tri_nrm = ctx->tri_nrm;
+    sc.sky = ctx->sky;
+    sc.sky_size = ctx->sky_size;
+    sc.t_min = ctx->settings.t_min;
+    sc.t_max = ctx->settings.t_max;
+    return sc;
+}
+
+int ensure_gstack(pt_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->gstack_bytes) return PT_OK;
+    dev_free(ctx->gstack);
+    ctx->gstack_bytes = 0;
+    PT_HIP(ctx, hipMalloc((void **)&ctx->gstack, bytes));
+    ctx->gstack_bytes = bytes;
+    return PT_OK;
+}
+
+inline float u2f(uint32_t u)
+{
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
+{
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: null output pointer");
+    *out = nullptr;
+    if (width == 0 || height == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: zero image size");
+    if ((uint64_t)width * height > (1ull << 30)) return fail(nullptr, PT_ERR_LIMIT, "pt_create: image larger than 2^30 pixels");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, PT_ERR_HIP, "pt_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, PT_ERR_INVALID, "pt_create: device %d out of range (%d present)", device, count);
+    pt_ctx *ctx = new (std::nothrow) pt_ctx();
+    if (!ctx) return fail(nullptr, PT_ERR_NOMEM, "pt_create: out of host memory");
+    ctx->device = device;
+    ctx->width = width;
+    ctx->height = height;
+    const size_t n = (size_t)width * height;
+    int rc = PT_OK;
+    auto step = [&](hipError_t he, const char *what) {
+        if (rc == PT_OK && he != hipSuccess)
+            rc = fail(nullptr, he == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(he));
+    };
+    step(hipSetDevice(device), "hipSetDevice");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->accum_owned, n * sizeof(float4)), "accumulation buffer");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_prim, n * sizeof(uint32_t)), "aov buffer");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_NUM_COUNTERS * sizeof(unsigned long long)), "counters");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 2 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
+    if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
+    if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
+    if (rc == PT_OK) step(hipMemset(ctx->aov_t, 0, n * sizeof(float)), "clear");
+    if (rc == PT_OK) step(hipMemset(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long)), "clear");
+    if (rc != PT_OK) {
+        pt_destroy(ctx);
+        return rc;
+    }
+    ctx->accum = ctx->accum_owned;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    else (void)hipDeviceSynchronize();
+    dev_free(ctx->accum_owned);
+    dev_free(ctx->aov_prim);
+    dev_free(ctx->aov_t);
+    dev_free(ctx->counters);
+    dev_free(ctx->spheres);
+    free_mesh(ctx);
+    dev_free(ctx->sky);
+    dev_free(ctx->gstack);
+    dev_free(ctx->scratch);
+    delete ctx;
+}
+
+int pt_set_stream(pt_ctx *ctx, void *hip_stream)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return PT_OK;
+}
+
+int pt_set_flags(pt_ctx *ctx, uint32_t flags)
+{
+    PT_ENTER(ctx);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    ctx->flags = flags;
+    return PT_OK;
+}
+
+int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // kernels in flight may still read the old mesh
+    if (n_nodes == 0) {
+        free_mesh(ctx);
+        return PT_OK;
+    }
+    if (!tris_v || !nodes_v || !tri_idx || n_tris == 0 || n_idx == 0) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: null or empty input with n_nodes=%u", n_nodes);
+    if (n_nodes >= (1u << 28) || n_idx >= (1u << 28)) return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: more than 2^28-1 nodes or indices");
+    const PtTriangle *tris = static_cast<const PtTriangle *>(tris_v);
+    const PtNode *nodes = static_cast<const PtNode *>(nodes_v);
+
+    // Validate, and find the deepest reachable node.  Children must be stored after their
+    // parent (the reference's builder guarantees it, bvh.rs:131-134), which rules out cycles.
+    std::vector<int32_t> depth(n_nodes, -1);
+    depth[0] = 0;
+    uint32_t max_depth = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (depth[i] < 0) continue;  // unreachable: never visited by traversal
+        const PtNode &n = nodes[i];
+        max_depth = std::max<uint32_t>(max_depth, (uint32_t)depth[i]);
+        if (n.triangle_count == 0) {
+            const uint64_t l = n.left_child_index;
+            if (l <= i || l + 1 >= n_nodes) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: node %u has children %llu,%llu outside (%u, %u)", i, (unsigned long long)l, (unsigned long long)l + 1, i, n_nodes);
+            depth[l] = std::max(depth[l], depth[i] + 1);
+            depth[l + 1] = std::max(depth[l + 1], depth[i] + 1);
+        } else {
+            const uint64_t end = (uint64_t)n.left_child_index + n.triangle_count;
+            if (end > n_idx) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: leaf %u covers indices [%u, %llu) beyond %u", i, n.left_child_index, (unsigned long long)end, n_idx);
+        }
+    }
+    for (uint32_t k = 0; k < n_idx; k++)
+        if (tri_idx[k] >= n_tris) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: triangle index %u at position %u out of range (%u triangles)", tri_idx[k], k, n_tris);
+
+    auto token_of = [&](uint32_t i) -> uint32_t {
+        const PtNode &n = nodes[i];
+        if (n.triangle_count == 0) return n.left_child_index;
+        if (n.triangle_count <= 7u) return PT_TOKEN_LEAF | (n.triangle_count << 28) | n.left_child_index;
+        return PT_TOKEN_LEAF | i;
+    };
+
+    std::vector<float4> h_nodes(2 * ((size_t)n_nodes + 1));
+    std::vector<uint2> h_meta(n_nodes);
+    h_nodes[0] = h_nodes[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const PtNode &n = nodes[i];
+        h_nodes[2 * ((size_t)i + 1)] = make_float4(n.min_corner[0], n.min_corner[1], n.min_corner[2], u2f(token_of(i)));
+        h_nodes[2 * ((size_t)i + 1) + 1] = make_float4(n.max_corner[0], n.max_corner[1], n.max_corner[2], u2f(n.triangle_count));
+        h_meta[i] = make_uint2(n.left_child_index, n.triangle_count);
+    }
+    std::vector<float4> h_pos(3 * (size_t)n_idx), h_nrm(3 * (size_t)n_idx);
+    for (uint32_t k = 0; k < n_idx; k++) {
+        const PtTriangle &t = tris[tri_idx[k]];
+        // edges as the shader computes them (compute.wgsl:353-354)
+        h_pos[3 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(tri_idx[k]));
+        h_pos[3 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], 0.0f);
+        h_pos[3 * (size_t)k + 2] = make_float4(t.c[0] - t.a[0], t.c[1] - t.a[1], t.c[2] - t.a[2], 0.0f);
+        h_nrm[3 * (size_t)k] = make_float4(t.na[0], t.na[1], t.na[2], 0.0f);
+        h_nrm[3 * (size_t)k + 1] = make_float4(t.nb[0], t.nb[1], t.nb[2], 0.0f);
+        h_nrm[3 * (size_t)k + 2] = make_float4(t.nc[0], t.nc[1], t.nc[2], 0.0f);
+    }
+
+    free_mesh(ctx);
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->nodes_alloc, h_nodes.size())) != PT_OK || (rc = dev_alloc(ctx, &ctx->node_meta, h_meta.size())) != PT_OK ||
+        (rc = dev_alloc(ctx, &ctx->tri_pos, h_pos.size())) != PT_OK || (rc = dev_alloc(ctx, &ctx->tri_nrm, h_nrm.size())) != PT_OK) {
+        free_mesh(ctx);
+        return rc;
+    }
+    PT_HIP(ctx, hipMemcpy(ctx->nodes_alloc, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->node_meta, h_meta.data(), h_meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->tri_pos, h_pos.data(), h_pos.size() * sizeof(float4), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->tri_nrm, h_nrm.data(), h_nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
+    ctx->n_nodes = n_nodes;
+    ctx->root_token = token_of(0);
+    ctx->bvh_depth = max_depth;
+    return PT_OK;
+}
+
+int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (size == 0) {
+        dev_free(ctx->sky);
+        ctx->sky_size = 0;
+        return PT_OK;
+    }
+    if (!rgba32f) return fail(ctx, PT_ERR_INVALID, "pt_set_sky_cube: null texels");
+    if (size > 16384u) return fail(ctx, PT_ERR_LIMIT, "pt_set_sky_cube: face size %u above 16384", size);
+    const size_t texels = 6 * (size_t)size * size;
+    if (ctx->sky_size != size) {
+        dev_free(ctx->sky);
+        ctx->sky_size = 0;
+        int rc = dev_alloc(ctx, &ctx->sky, texels);
+        if (rc != PT_OK) return rc;
+    }
+    PT_HIP(ctx, hipMemcpy(ctx->sky, rgba32f, texels * sizeof(float4), hipMemcpyHostToDevice));
+    ctx->sky_size = size;
+    return PT_OK;
+}
+
+int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!rgba32f || w == 0 || h == 0 || cube_size == 0) return fail(ctx, PT_ERR_INVALID, "pt_set_sky_equirect: null or empty input");
+    if (cube_size > 16384u || w > 32768u || h > 32768u) return fail(ctx, PT_ERR_LIMIT, "pt_set_sky_equirect: size above limit");
+    const size_t texels = 6 * (size_t)cube_size * cube_size;
+    if (ctx->sky_size != cube_size) {
+        dev_free(ctx->sky);
+        ctx->sky_size = 0;
+        int rc = dev_alloc(ctx, &ctx->sky, texels);
+        if (rc != PT_OK) return rc;
+    }
+    float4 *src = nullptr;
+    PT_HIP(ctx, hipMalloc((void **)&src, (size_t)w * h * sizeof(float4)));
+    hipError_t e = hipMemcpy(src, rgba32f, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pt_launch_equirect(src, w, h, ctx->sky, cube_size, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(src);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_set_sky_equirect: %s", hipGetErrorString(e));
+    ctx->sky_size = cube_size;
+    return PT_OK;
+}
+
+int pt_read_sky_cube(pt_ctx *ctx, float *out)
+{
+    PT_ENTER(ctx);
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_sky_cube: null output");
+    if (!ctx->sky_size) return fail(ctx, PT_ERR_STATE, "pt_read_sky_cube: no sky set");
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->sky, 6 * (size_t)ctx->sky_size * ctx->sky_size * sizeof(float4), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx *ctx, const void *camera64)
+{
+    PT_ENTER(ctx);
+    if (!camera64) return fail(ctx, PT_ERR_INVALID, "pt_set_camera: null pointer");
+    std::memcpy(&ctx->camera, camera64, sizeof(PtCamera));
+    ctx->have_camera = true;
+    return PT_OK;
+}
+
+int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
+{
+    PT_ENTER(ctx);
+    if (!sphere_data8208) return fail(ctx, PT_ERR_INVALID, "pt_set_spheres: null pointer");
+    const PtSphereData *sd = static_cast<const PtSphereData *>(sphere_data8208);
+    // the storage buffer holds 256 spheres; a larger count would read past it
+    const uint32_t n = sd->sphere_count > PT_MAX_SPHERES ? PT_MAX_SPHERES : sd->sphere_count;
+    // stream-ordered copy from pageable memory: the runtime stages the bytes before returning
+    if (n) PT_HIP(ctx, hipMemcpyAsync(ctx->spheres, sd->spheres, (size_t)n * sizeof(PtSphere), hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_spheres = n;
+    return PT_OK;
+}
+
+int pt_set_settings(pt_ctx *ctx, const void *settings16)
+{
+    PT_ENTER(ctx);
+    if (!settings16) return fail(ctx, PT_ERR_INVALID, "pt_set_settings: null pointer");
+    std::memcpy(&ctx->settings, settings16, sizeof(PtSettings));
+    return PT_OK;
+}
+
+int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames)
+{
+    PT_ENTER(ctx);
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "pt_render: no camera set");
+    if (n_frames == 0) return PT_OK;
+    if (ctx->settings.samples_per_pixel == 0) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel is 0 (the shader would divide by zero)");
+    // per-lane ray counter is 32 bits
+    const uint64_t worst = (uint64_t)n_frames * ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);
+    if (worst >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render: n_frames*spp*depth too large for one launch; split the call");
+
+    PtTraceParams p{};
+    p.sc = device_scene(ctx);
+    p.fr = pt_camera_frame(reinterpret_cast<const float *>(&ctx->camera), ctx->width, ctx->height);
+    p.width = ctx->width;
+    p.height = ctx->height;
+    p.cols = ctx->width;
+    p.rows = ctx->height;
+    if (ctx->flags & PT_FLAG_REFERENCE_DISPATCH) {
+        p.cols = (ctx->width / 16u) * 16u;
+        p.rows = (ctx->height / 16u) * 16u;
+    }
+    p.spp = ctx->settings.samples_per_pixel;
+    p.depth = ctx->settings.depth;
+    p.time0 = time0;
+    p.stride = stride;
+    p.n_frames = n_frames;
+    p.accum = ctx->accum;
+    p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
+    p.aov_t = ctx->aov_t;
+    p.counters = ctx->counters;
+    const size_t gs = pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
+    if (gs) {
+        int rc = ensure_gstack(ctx, gs);
+        if (rc != PT_OK) return rc;
+    }
+    p.gstack = ctx->gstack;
+    p.gstack_cap = gs ? ctx->bvh_depth : 0;
+    PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, ctx->stream));
+    ctx->frames += n_frames;
+    return PT_OK;
+}
+
+int pt_render(pt_ctx *ctx, uint32_t time) { return pt_render_frames(ctx, time, 0, 1); }
+
+int pt_reset(pt_ctx *ctx)
+{
+    PT_ENTER(ctx);
+    const size_t n = (size_t)ctx->width * ctx->height;
+    PT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, n * sizeof(float4), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    ctx->frames = 0;
+    return PT_OK;
+}
+
+int pt_sync(pt_ctx *ctx)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
+{
+    PT_ENTER(ctx);
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_sum_rgba32f: null output");
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
+{
+    PT_ENTER(ctx);
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_mean_rgba32f: null output");
+    const uint32_t n = ctx->width * ctx->height;
+    int rc = ensure_scratch(ctx, (size_t)n * sizeof(float4));
+    if (rc != PT_OK) return rc;
+    PT_HIP(ctx, pt_launch_resolve(ctx->accum, n, static_cast<float4 *>(ctx->scratch), nullptr, 0, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->scratch, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
+{
+    PT_ENTER(ctx);
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_rgba8: null output");
+    const uint32_t n = ctx->width * ctx->height;
+    int rc = ensure_scratch(ctx, (size_t)n * sizeof(float4));
+    if (rc != PT_OK) return rc;
+    PT_HIP(ctx, pt_launch_resolve(ctx->accum, n, nullptr, static_cast<uint32_t *>(ctx->scratch), 1, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->scratch, (size_t)n * 4u, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)ctx->width * ctx->height;
+    if (prim) PT_HIP(ctx, hipMemcpy(prim, ctx->aov_prim, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (t) PT_HIP(ctx, hipMemcpy(t, ctx->aov_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_stats(pt_ctx *ctx, pt_stats_t *out)
+{
+    PT_ENTER(ctx);
+    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_stats: null output");
+    unsigned long long c[PT_NUM_COUNTERS];
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof c, hipMemcpyDeviceToHost));
+    out->rays = c[0];
+    out->paths = c[1];
+    out->interior = c[2];
+    out->tri_tests = c[3];
+    out->tri_accept = c[4];
+    out->sphere_tests = c[5];
+    out->sky_lookups = c[6];
+    out->bounces = c[7];
+    out->frames = ctx->frames;
+    out->bvh_depth = ctx->bvh_depth;
+    return PT_OK;
+}
+
+void *pt_accum_device_ptr(pt_ctx *ctx) { return ctx ? ctx->accum : nullptr; }
+
+int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
+{
+    PT_ENTER(ctx);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u)) return fail(ctx, PT_ERR_INVALID, "pt_bind_accum: pointer not 16-byte aligned");
+    ctx->accum = device_ptr ? static_cast<float4 *>(device_ptr) : ctx->accum_owned;
+    return PT_OK;
+}
+
+int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
+{
+    PT_ENTER(ctx);
+    if (n == 0) return PT_OK;
+    if (!origins || !dirs) return fail(ctx, PT_ERR_INVALID, "pt_trace_rays: null rays");
+    if (n > (1u << 28)) return fail(ctx, PT_ERR_LIMIT, "pt_trace_rays: more than 2^28 rays");
+    // one allocation: origins | dirs | prim | t | p | normal | front
+    const size_t fl = (size_t)n * sizeof(float);
+    const size_t total = 3 * fl * 2 + fl + fl + 3 * fl * 2 + fl;
+    char *buf = nullptr;
+    PT_HIP(ctx, hipMalloc((void **)&buf, total));
+    PtRayQuery q{};
+    q.sc = device_scene(ctx);
+    char *cur = buf;
+    q.origins = reinterpret_cast<float *>(cur); cur += 3 * fl;
+    q.dirs = reinterpret_cast<float *>(cur); cur += 3 * fl;
+    q.prim = reinterpret_cast<uint32_t *>(cur); cur += fl;
+    q.t = reinterpret_cast<float *>(cur); cur += fl;
+    q.p = reinterpret_cast<float *>(cur); cur += 3 * fl;
+    q.normal = reinterpret_cast<float *>(cur); cur += 3 * fl;
+    q.front = reinterpret_cast<uint32_t *>(cur);
+    q.n = n;
+    uint32_t *gs_mem = nullptr;
+    const size_t gs = pt_ray_query_gstack_bytes(n, ctx->bvh_depth);
+    hipError_t e = hipSuccess;
+    if (gs) e = hipMalloc((void **)&gs_mem, gs);
+    q.gstack = gs_mem;
+    q.gstack_cap = gs ? ctx->bvh_depth : 0;
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)q.origins, origins, 3 * fl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)q.dirs, dirs, 3 * fl, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = pt_launch_ray_query(q, ctx->bvh_depth, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && prim) e = hipMemcpy(prim, q.prim, fl, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && t) e = hipMemcpy(t, q.t, fl, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && p) e = hipMemcpy(p, q.p, 3 * fl, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && normal) e = hipMemcpy(normal, q.normal, 3 * fl, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && front) e = hipMemcpy(front, q.front, fl, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (gs_mem) (void)hipFree(gs_mem);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "pt_trace_rays: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// pt_host.cpp -- host-side scene construction: the CPU code of the reference that produces
+// the kernel's inputs (BVH build, plane tessellation, sphere packing, .obj ingestion).
+// No GPU calls.  Built with -ffp-contract=off: Rust never fuses a*b+c, and the BVH must come
+// out identical to the reference's, node for node.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrt.h"
+#include "pt_layout.h"
+
+namespace {
+
+thread_local std::string g_host_error;
+
+int host_fail(int code, const std::string &msg)
+{
+    g_host_error = msg;
+    return code;
+}
+
+// Triangle::centroid, src/model.rs:42-48
+inline float centroid_axis(const PtTriangle &t, int axis) { return (t.a[axis] + t.b[axis] + t.c[axis]) / 3.0f; }
+
+struct BvhBuilder {
+    PtNode *nodes;
+    uint32_t *idx;
+    const PtTriangle *tris;
+    uint32_t used;
+
+    // Bvh::update_bounds, src/scene/bvh.rs:68-89 (f32::min/max ignore a NaN operand, as fminf/fmaxf do)
+    void update_bounds(uint32_t ni)
+    {
+        PtNode &n = nodes[ni];
+        for (uint32_t i = 0; i < n.triangle_count; i++) {
+            const PtTriangle &t = tris[idx[n.left_child_index + i]];
+            const float *verts[3] = {t.a, t.b, t.c};
+            for (const float *v : verts)
+                for (int ax = 0; ax < 3; ax++) {
+                    n.min_corner[ax] = std::fmin(n.min_corner[ax], v[ax]);
+                    n.max_corner[ax] = std::fmax(n.max_corner[ax], v[ax]);
+                }
+        }
+    }
+
+    // Bvh::subdivide, src/scene/bvh.rs:91-162.  Returns false when the node stays a leaf,
+    // otherwise the two children (left, left+1) are allocated and bounded.
+    bool split(uint32_t ni)
+    {
+        const PtNode node = nodes[ni];
+        if (node.triangle_count <= 2) return false;
+        const float extent[3] = {node.max_corner[0] - node.min_corner[0], node.max_corner[1] - node.min_corner[1],
+                                 node.max_corner[2] - node.min_corner[2]};
+        int axis = 0;
+        if (extent[1] > extent[axis]) axis = 1;
+        if (extent[2] > extent[axis]) axis = 2;
+        const float split_position = node.min_corner[axis] + extent[axis] / 2.0f;
+
+        // the reference's loop stops at i == j, so the element there is never compared and
+        // lands on the right-hand side
+        uint32_t i = node.left_child_index, j = node.left_child_index + node.triangle_count - 1u;
+        while (i < j) {
+            if (centroid_axis(tris[idx[i]], axis) < split_position) i++;
+            else std::swap(idx[i], idx[j--]);
+        }
+        const uint32_t left_count = i - node.left_child_index;
+        if (left_count == 0 || left_count == node.triangle_count) return false;
+
+        const uint32_t li = used++, ri = used++;
+        nodes[li].left_child_index = node.left_child_index;
+        nodes[li].triangle_count = left_count;
+        nodes[ri].left_child_index = i;
+        nodes[ri].triangle_count = node.triangle_count - left_count;
+        nodes[ni].left_child_index = li;
+        nodes[ni].triangle_count = 0;
+        update_bounds(li);
+        update_bounds(ri);
+        return true;
+    }
+
+    // Same visiting order as the reference's recursion (whole left subtree before the right
+    // one, which fixes the node numbering) with an explicit stack, so clustered input cannot
+    // overflow the call stack.
+    void build(uint32_t n_tris)
+    {
+        nodes[0].left_child_index = 0;
+        nodes[0].triangle_count = n_tris;
+        used = 1;
+        update_bounds(0);
+        std::vector<uint32_t> todo{0};
+        while (!todo.empty()) {
+            const uint32_t ni = todo.back();
+            todo.pop_back();
+            if (split(ni)) {
+                const uint32_t li = nodes[ni].left_child_index;
+                todo.push_back(li + 1);
+                todo.push_back(li);
+            }
+        }
+    }
+};
+
+struct ObjVertexRef {
+    int v, vn;
+};
+
+bool parse_index(const char *&s, int count, int &out)
+{
+    char *end = nullptr;
+    const long raw = std::strtol(s, &end, 10);
+    if (end == s) return false;
+    s = end;
+    if (raw > 0) out = (int)(raw - 1);
+    else if (raw < 0) out = count + (int)raw;
+    else return false;
+    return out >= 0 && out < count;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_host_error(void) { return g_host_error.c_str(); }
+
+int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
+{
+    if (n_tris == 0) return 0;  // Bvh::from_triangles returns empty vectors, bvh.rs:35-41
+    if (!tris || !nodes_out || !idx_out) return host_fail(PT_ERR_INVALID, "pt_bvh_build: null pointer");
+    PtNode *nodes = static_cast<PtNode *>(nodes_out);
+    const size_t cap = (size_t)n_tris * 2u - 1u;
+    for (size_t k = 0; k < cap; k++) {  // Node::default, bvh.rs:16-25
+        for (int ax = 0; ax < 3; ax++) {
+            nodes[k].min_corner[ax] = 3.40282347e+38f;
+            nodes[k].max_corner[ax] = -3.40282347e+38f;
+        }
+        nodes[k].left_child_index = 0;
+        nodes[k].triangle_count = 0;
+    }
+    for (uint32_t k = 0; k < n_tris; k++) idx_out[k] = k;
+    BvhBuilder b{nodes, idx_out, static_cast<const PtTriangle *>(tris), 0};
+    b.build(n_tris);
+    return (int64_t)b.used;
+}
+
+int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3], uint32_t material,
+                       void *tris_out)
+{
+    if (!q || !u || !v || !albedo || !tris_out) return host_fail(PT_ERR_INVALID, "pt_plane_triangles: null pointer");
+    // Plane::normal, plane.rs:43-45: cgmath cross then normalize = v * (1 / sqrt(x*x + y*y + z*z))
+    const float cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+    const float inv = 1.0f / std::sqrt(cx * cx + cy * cy + cz * cz);
+    const float n[3] = {cx * inv, cy * inv, cz * inv};
+    float qu[3], qv[3], quv[3];
+    for (int ax = 0; ax < 3; ax++) {
+        qu[ax] = q[ax] + u[ax];
+        qv[ax] = q[ax] + v[ax];
+        quv[ax] = qu[ax] + v[ax];
+    }
+    PtTriangle *out = static_cast<PtTriangle *>(tris_out);
+    std::memset(out, 0, 2 * sizeof(PtTriangle));
+    for (int k = 0; k < 2; k++) {
+        const float *first = (k == 0) ? q : quv;  // plane.rs:18-38
+        for (int ax = 0; ax < 3; ax++) {
+            out[k].a[ax] = first[ax];
+            out[k].b[ax] = qu[ax];
+            out[k].c[ax] = qv[ax];
+            out[k].na[ax] = out[k].nb[ax] = out[k].nc[ax] = n[ax];
+            out[k].albedo[ax] = albedo[ax];
+        }
+        out[k].material = material;
+    }
+    return PT_OK;
+}
+
+int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data_out)
+{
+    if ((!spheres8 && n) || !sphere_data_out) return host_fail(PT_ERR_INVALID, "pt_pack_spheres: null pointer");
+    PtSphereData *out = static_cast<PtSphereData *>(sphere_data_out);
+    std::memset(out, 0, sizeof(PtSphereData));
+    const uint32_t kept = std::min<uint32_t>(n, PT_MAX_SPHERES);  // sphere.rs:116-125
+    out->sphere_count = kept;
+    if (kept) std::memcpy(out->spheres, spheres8, (size_t)kept * sizeof(PtSphere));
+    return PT_OK;
+}
+
+int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris)
+{
+    if (!path || !n_tris) return host_fail(PT_ERR_INVALID, "pt_obj_load: null pointer");
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return host_fail(PT_ERR_INVALID, std::string("pt_obj_load: cannot open ") + path);
+    std::vector<float> pos, nrm;
+    std::vector<ObjVertexRef> corners;  // three per triangle after fan triangulation
+    std::vector<char> line(1 << 16);
+    bool bad = false;
+    std::string why;
+    while (std::fgets(line.data(), (int)line.size(), fp)) {
+        const char *s = line.data();
+        while (*s == ' ' || *s == '\t') s++;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            char *e = nullptr;
+            s += 2;
+            for (int k = 0; k < 3; k++) { pos.push_back(std::strtof(s, &e)); if (e == s) { bad = true; why = "malformed v line"; } s = e; }
+        } else if (s[0] == 'v' && s[1] == 'n' && (s[2] == ' ' || s[2] == '\t')) {
+            char *e = nullptr;
+            s += 3;
+            for (int k = 0; k < 3; k++) { nrm.push_back(std::strtof(s, &e)); if (e == s) { bad = true; why = "malformed vn line"; } s = e; }
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            s += 2;
+            std::vector<ObjVertexRef> poly;
+            for (;;) {
+                while (*s == ' ' || *s == '\t') s++;
+                if (*s == '\0' || *s == '\n' || *s == '\r' || *s == '#') break;
+                ObjVertexRef r{-1, -1};
+                if (!parse_index(s, (int)(pos.size() / 3), r.v)) { bad = true; why = "bad vertex index in f line"; break; }
+                if (*s == '/') {
+                    s++;
+                    if (*s != '/') { int vt; char *e; (void)vt; std::strtol(s, &e, 10); s = e; }  // texture index unused
+                    if (*s == '/') {
+                        s++;
+                        if (!parse_index(s, (int)(nrm.size() / 3), r.vn)) { bad = true; why = "bad normal index in f line"; break; }
+                    }
+                }
+                poly.push_back(r);
+            }
+            if (bad) break;
+            for (size_t k = 1; k + 1 < poly.size(); k++) {  // fan: (0, k, k+1)
+                corners.push_back(poly[0]);
+                corners.push_back(poly[k]);
+                corners.push_back(poly[k + 1]);
+            }
+        }
+        if (bad) break;
+    }
+    std::fclose(fp);
+    if (bad) return host_fail(PT_ERR_INVALID, "pt_obj_load: " + why);
+    const size_t count = corners.size() / 3;
+    if (count > 0xFFFFFFFFull) return host_fail(PT_ERR_LIMIT, "pt_obj_load: too many triangles");
+    *n_tris = (uint32_t)count;
+    if (!tris_out) return PT_OK;
+    if (capacity < count) return host_fail(PT_ERR_INVALID, "pt_obj_load: output buffer too small");
+
+    // vertices without a vn reference: area-weighted smooth normals per position index
+    std::vector<float> smooth;
+    bool need_smooth = false;
+    for (const ObjVertexRef &r : corners) need_smooth |= (r.vn < 0);
+    if (need_smooth) {
+        smooth.assign(pos.size(), 0.0f);
+        for (size_t t = 0; t < count; t++) {
+            const float *a = &pos[3 * corners[3 * t].v], *b = &pos[3 * corners[3 * t + 1].v], *c = &pos[3 * corners[3 * t + 2].v];
+            const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            const float fn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            for (int k = 0; k < 3; k++)
+                for (int ax = 0; ax < 3; ax++) smooth[3 * corners[3 * t + k].v + ax] += fn[ax];
+        }
+        for (size_t i = 0; i + 2 < smooth.size(); i += 3) {
+            const float len = std::sqrt(smooth[i] * smooth[i] + smooth[i + 1] * smooth[i + 1] + smooth[i + 2] * smooth[i + 2]);
+            if (len > 0.0f) { smooth[i] /= len; smooth[i + 1] /= len; smooth[i + 2] /= len; }
+            else { smooth[i] = 0.0f; smooth[i + 1] = 1.0f; smooth[i + 2] = 0.0f; }
+        }
+    }
+    PtTriangle *out = static_cast<PtTriangle *>(tris_out);
+    std::memset(out, 0, count * sizeof(PtTriangle));
+    for (size_t t = 0; t < count; t++) {
+        float *pdst[3] = {out[t].a, out[t].b, out[t].c}, *ndst[3] = {out[t].na, out[t].nb, out[t].nc};
+        for (int k = 0; k < 3; k++) {
+            const ObjVertexRef r = corners[3 * t + k];
+            std::memcpy(pdst[k], &pos[3 * r.v], 12);
+            std::memcpy(ndst[k], r.vn >= 0 ? &nrm[3 * r.vn] : &smooth[3 * r.v], 12);
+        }
+        out[t].albedo[0] = out[t].albedo[1] = out[t].albedo[2] = 1.0f;  // model.rs:199-200
+        out[t].material = 0;
+    }
+    return PT_OK;
+}
+
+}  // extern "C"

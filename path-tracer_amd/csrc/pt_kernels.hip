@@ -1,0 +1,581 @@
+// pt_kernels.hip -- gfx950 kernels of the path-tracing hot path.
+//
+// One lane owns one pixel and walks it through all requested frames: camera ray
+// (compute.wgsl:83-128), bounce loop (:130-207), closest hit over spheres and the flattened
+// BVH (:214-302, :304-406, :441-456), material scatter with the shader's hash RNG
+// (utils.wgsl), sky cube lookup (:209-212) and the fp32 running sum.  Every floating-point
+// step follows pt_math.h so results are bit-identical to a scalar evaluation of the same
+// sequence; the file must be compiled with -ffp-contract=off and without fast-math.
+//
+// CDNA4 mapping: wave64, one wave = an 8x8 pixel tile; the traversal stack holds 4-byte node
+// tokens in LDS laid out [entry][lane] (conflict-free for any mix of stack depths); the two
+// children of an interior node are one 64-byte aligned fetch; leaf triangles are stored in
+// leaf order (no index indirection) as {a, b-a, c-a}, normals are fetched once per closest hit;
+// sphere records are wave-uniform loads.  A lane that finishes a path starts its next
+// sample/frame immediately, so a wave only idles when every lane has run out of frames.
+#include "pt_kernels.h"
+
+namespace {
+
+struct Ray {
+    v3 o, d;
+};
+
+__device__ __forceinline__ v3 f4_xyz(float4 a) { return V3(a.x, a.y, a.z); }
+
+// ---- traversal stack ---------------------------------------------------------------------
+// Entries 0..PT_LDS_STACK-1 live in LDS at [entry][lane]; deeper entries (only trees deeper
+// than PT_LDS_STACK, and then only the rays that actually get that deep) spill to a
+// per-thread column of a global buffer.
+template <bool OVERFLOW>
+struct Stack {
+    uint32_t *lds;     // &smem[threadIdx.x]; entry e at lds[e * PT_BLOCK]
+    uint32_t *spill;   // &gstack[global thread]; entry e at spill[(e - PT_LDS_STACK) * pitch]
+    size_t pitch;
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
+    {
+        if (!OVERFLOW || sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = v;
+        else spill[(size_t)(sp - PT_LDS_STACK) * pitch] = v;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp)
+    {
+        if (!OVERFLOW || sp < PT_LDS_STACK) return lds[sp * PT_BLOCK];
+        return spill[(size_t)(sp - PT_LDS_STACK) * pitch];
+    }
+};
+
+struct Counters {
+    uint32_t rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces;
+};
+
+// Closest-hit record kept in registers during traversal; the full record (point, normal,
+// attenuation) is derived once from it afterwards.
+struct Closest {
+    bool hit;
+    bool is_tri;
+    float t;
+    uint32_t index;  // sphere index, or leaf-order triangle slot
+    float u, v;
+};
+
+struct HitRecord {
+    bool hit;
+    float t;
+    v3 p, normal;
+    bool front;
+    v3 att;
+    float material;
+    uint32_t prim;
+};
+
+// hitAabb, compute.wgsl:441-456, with 1/direction hoisted out (same correctly rounded value).
+__device__ __forceinline__ float hit_aabb(v3 o, v3 inv, float4 lo, float4 hi)
+{
+    const v3 t1 = (f4_xyz(lo) - o) * inv;
+    const v3 t2 = (f4_xyz(hi) - o) * inv;
+    const float tmin = pt_max(pt_max(pt_min(t1.x, t2.x), pt_min(t1.y, t2.y)), pt_min(t1.z, t2.z));
+    const float tmax = pt_min(pt_min(pt_max(t1.x, t2.x), pt_max(t1.y, t2.y)), pt_max(t1.z, t2.z));
+    return (tmin > tmax || tmax < 0.0f) ? 99999.0f : tmin;
+}
+
+// hitScene, compute.wgsl:214-302.  Spheres in array order, then the BVH with the shader's
+// own near-first order, prune rule (nearest updated by triangle hits only) and strict '<'.
+template <bool STATS, typename StackT>
+__device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray &ray, StackT stack, Counters &cn)
+{
+    Closest rec;
+    rec.hit = false;
+    rec.is_tri = false;
+    rec.t = 0.0f;
+    rec.index = 0;
+    rec.u = rec.v = 0.0f;
+
+    const v3 o = ray.o, d = ray.d;
+    // hitSphere, compute.wgsl:304-350
+    {
+        const float a = dot3(d, d);
+        const float den = 2.0f * a;
+        const float a4 = 4.0f * a;
+        for (uint32_t i = 0; i < sc.n_spheres; i++) {
+            const float4 s0 = sc.spheres[2 * i];
+            const v3 c = f4_xyz(s0);
+            const float r = s0.w;
+            if (STATS) cn.sphere_tests++;
+            const v3 oc = o - c;
+            const float b = 2.0f * dot3(d, oc);
+            const float cc = pt_fma(-r, r, dot3(oc, oc));
+            const float disc = pt_fma(b, b, -(a4 * cc));
+            if (disc < 0.0f) continue;
+            const float sq = pt_sqrt(disc);
+            float root = (-b - sq) / den;
+            if (root <= sc.t_min || root >= sc.t_max) root = (-b + sq) / den;
+            if (root <= sc.t_min || root >= sc.t_max) continue;
+            const float mat = sc.spheres[2 * i + 1].w;
+            if (mat >= 3.0f && mat < 4.0f) {  // gizmo ring filter, compute.wgsl:342-347
+                const v3 p = v3_fma(root, d, o);
+                const v3 on = (p - c) / r;
+                const bool front = dot3(d, on) < 0.0f;
+                const v3 n = front ? on : -on;
+                const float dn = dot3(d, n);
+                if (!(dn <= 0.2f && dn >= -0.2f)) continue;
+            }
+            if (!rec.hit || root < rec.t) {
+                rec.hit = true;
+                rec.t = root;
+                rec.index = i;
+            }
+        }
+    }
+
+    if (sc.n_nodes == 0) return rec;
+
+    const v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float nearest = 9999.0f;
+    uint32_t cur = sc.root_token;
+    uint32_t sp = 0;
+    for (;;) {
+        if (!(cur & PT_TOKEN_LEAF)) {
+            if (STATS) cn.interior++;
+            const float4 *pn = sc.nodes + 2 * (size_t)cur;  // children cur, cur+1: 64 contiguous bytes
+            const float4 l0 = pn[0], l1 = pn[1], r0 = pn[2], r1 = pn[3];
+            float d1 = hit_aabb(o, inv, l0, l1);
+            float d2 = hit_aabb(o, inv, r0, r1);
+            uint32_t k1 = __float_as_uint(l0.w), k2 = __float_as_uint(r0.w);
+            if (d1 > d2) {
+                const float td = d1; d1 = d2; d2 = td;
+                const uint32_t tk = k1; k1 = k2; k2 = tk;
+            }
+            if (d1 > nearest) {
+                if (sp == 0) break;
+                cur = stack.pop(--sp);
+            } else {
+                cur = k1;
+                if (d2 < nearest) stack.push(sp++, k2);
+            }
+        } else {
+            uint32_t count = (cur >> 28) & 7u, first = cur & PT_TOKEN_LOW;
+            if (count == 0) {
+                const uint2 m = sc.node_meta[first];
+                first = m.x;
+                count = m.y;
+            }
+            // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
+            for (uint32_t k = 0; k < count; k++) {
+                const uint32_t slot = first + k;
+                const float4 *tp = sc.tri_pos + 3 * (size_t)slot;
+                const float4 A4 = tp[0], E1 = tp[1], E2 = tp[2];
+                if (STATS) cn.tri_tests++;
+                const v3 e1 = f4_xyz(E1), e2 = f4_xyz(E2);
+                const v3 h = cross3(d, e2);
+                const float a = dot3(e1, h);
+                if (a > -0.00001f && a < 0.00001f) continue;
+                const float f = 1.0f / a;
+                const v3 s = o - f4_xyz(A4);
+                const float u = f * dot3(s, h);
+                if (u < 0.0f || u > 1.0f) continue;
+                const v3 q = cross3(s, e1);
+                const float v = f * dot3(d, q);
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = f * dot3(e2, q);
+                if (t <= sc.t_min || t >= sc.t_max) continue;
+                if (!rec.hit || t < rec.t) {
+                    rec.hit = true;
+                    rec.is_tri = true;
+                    rec.t = t;
+                    rec.index = slot;
+                    rec.u = u;
+                    rec.v = v;
+                    nearest = t;
+                    if (STATS) cn.tri_accept++;
+                }
+            }
+            if (sp == 0) break;
+            cur = stack.pop(--sp);
+        }
+    }
+    return rec;
+}
+
+// Expands the closest hit into the shader's HitRecord (compute.wgsl:334-340, 394-403).
+__device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const Ray &ray, const Closest &c)
+{
+    HitRecord h;
+    h.hit = c.hit;
+    h.t = c.t;
+    h.prim = 0xFFFFFFFFu;
+    h.p = h.normal = h.att = V3(0.0f, 0.0f, 0.0f);
+    h.front = false;
+    h.material = 0.0f;
+    if (!c.hit) return h;
+    h.p = v3_fma(c.t, ray.d, ray.o);
+    v3 on;
+    if (c.is_tri) {
+        const float4 *tn = sc.tri_nrm + 3 * (size_t)c.index;
+        const v3 an = f4_xyz(tn[0]), bn = f4_xyz(tn[1]), cnn = f4_xyz(tn[2]);
+        const float w = (1.0f - c.u) - c.v;
+        const v3 n = V3(pt_fma(cnn.x, c.v, pt_fma(bn.x, c.u, an.x * w)), pt_fma(cnn.y, c.v, pt_fma(bn.y, c.u, an.y * w)),
+                        pt_fma(cnn.z, c.v, pt_fma(bn.z, c.u, an.z * w)));
+        on = normalize3(n);
+        h.att = V3(1.0f, 1.0f, 1.0f);  // triangle albedo/material are ignored: compute.wgsl:359-367
+        h.material = 0.0f;
+        h.prim = __float_as_uint(sc.tri_pos[3 * (size_t)c.index].w);
+    } else {
+        const float4 s0 = sc.spheres[2 * c.index], s1 = sc.spheres[2 * c.index + 1];
+        on = (h.p - f4_xyz(s0)) / s0.w;
+        h.att = f4_xyz(s1);
+        h.material = s1.w;
+        h.prim = 0x80000000u | c.index;
+    }
+    h.front = dot3(ray.d, on) < 0.0f;
+    h.normal = h.front ? on : -on;
+    return h;
+}
+
+// getBackgroundColor, compute.wgsl:209-212: cube face by major axis (ties z, y, x), nearest
+// texel, clamp to edge.
+__device__ __forceinline__ v3 sky_lookup(const PtDeviceScene &sc, v3 d)
+{
+    if (sc.sky_size == 0) return V3(0.0f, 0.0f, 0.0f);
+    const float ax = pt_abs(d.x), ay = pt_abs(d.y), az = pt_abs(d.z);
+    uint32_t face;
+    float scoord, tcoord, ma;
+    if (az >= ax && az >= ay) {
+        face = d.z < 0.0f ? 5u : 4u; scoord = d.z < 0.0f ? -d.x : d.x; tcoord = -d.y; ma = az;
+    } else if (ay >= ax) {
+        face = d.y < 0.0f ? 3u : 2u; scoord = d.x; tcoord = d.y < 0.0f ? -d.z : d.z; ma = ay;
+    } else {
+        face = d.x < 0.0f ? 1u : 0u; scoord = d.x < 0.0f ? d.z : -d.z; tcoord = -d.y; ma = ax;
+    }
+    const float size = (float)sc.sky_size;
+    const float fs = pt_fma(0.5f, scoord / ma, 0.5f) * size;
+    const float ft = pt_fma(0.5f, tcoord / ma, 0.5f) * size;
+    const uint32_t hi = sc.sky_size - 1u;
+    const uint32_t i = (fs >= 0.0f) ? (fs < size ? (uint32_t)fs : hi) : 0u;
+    const uint32_t j = (ft >= 0.0f) ? (ft < size ? (uint32_t)ft : hi) : 0u;
+    const float4 tx = sc.sky[((size_t)face * sc.sky_size + j) * sc.sky_size + i];
+    return V3(tx.x, tx.y, tx.z);
+}
+
+// scatter / reflect / reflectance / refract: compute.wgsl:408-439
+__device__ __forceinline__ v3 scatter_dir(v3 dir, v3 normal, float seed)
+{
+    v3 s = normal + pt_random_unit(dir.x * seed, dir.y * seed);
+    if (pt_abs(s.x) < 1e-8f && pt_abs(s.y) < 1e-8f && pt_abs(s.z) < 1e-8f) s = normal;
+    return s;
+}
+__device__ __forceinline__ v3 reflect_dir(v3 dir, v3 normal)
+{
+    const float k = 2.0f * dot3(dir, normal);
+    return normalize3(v3_fma(-k, normal, dir));  // the fuzz term has weight 0 and is dropped
+}
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx)
+{
+    const float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    const float r0s = r0 * r0;
+    const float x = 1.0f - cosine, x2 = x * x;
+    const float p5 = (x2 * x2) * x;
+    return pt_fma(1.0f - r0s, p5, r0s);
+}
+__device__ __forceinline__ v3 refract_dir(v3 dir, v3 normal, float eta)
+{
+    const float cos_t = pt_min(dot3(-dir, normal), 1.0f);
+    const v3 perp = v3_fma(cos_t, normal, dir) * eta;
+    const float par = -pt_sqrt(pt_abs(1.0f - dot3(perp, perp)));
+    return v3_fma(par, normal, perp);
+}
+__device__ __forceinline__ uint32_t material_u32(float m)  // WGSL u32(f32): truncate, saturate, NaN -> 0
+{
+    if (!(m >= 0.0f)) return 0u;
+    if (m >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)m;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- the megakernel ---------------------------------------------------------------------
+template <bool STATS, bool OVERFLOW>
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
+{
+    // 16x16 pixel block tile; wave w covers the 8x8 sub-tile (w&1, w>>1); lane -> (l&7, l>>3)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+
+    __shared__ uint32_t smem[PT_LDS_STACK * PT_BLOCK];
+    Stack<OVERFLOW> stack{&smem[tid], nullptr, 0};
+    if (OVERFLOW) {
+        stack.spill = P.gstack + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PT_BLOCK + tid);
+        stack.pitch = (size_t)gridDim.x * gridDim.y * PT_BLOCK;
+    }
+
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool active = (x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0;
+
+    const PtDeviceScene &sc = P.sc;
+    const size_t pix = (size_t)y * P.width + x;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (active) acc = P.accum[pix];
+
+    // compute.wgsl:109
+    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
+    const float fspp = (float)P.spp;
+
+    uint32_t frame = 0, sample = 0;
+    uint32_t sx = 0, sy = 0, sz = 0, sw = 0;  // HybridTaus state
+    v3 frame_sum = V3(0.0f, 0.0f, 0.0f);
+    // per-path state
+    Ray cur;
+    cur.o = cur.d = V3(0.0f, 0.0f, 0.0f);
+    v3 initial_d = V3(0.0f, 0.0f, 0.0f);
+    v3 color = V3(1.0f, 1.0f, 1.0f);
+    float seed = 0.0f;
+    uint32_t bounce = 0, limit = 0;  // limit = depth + correction
+    bool need_new = true;
+    bool want_aov = false;
+
+    // Retire finished paths and start new ones until this lane holds a ray to trace (or is done).
+    // path_done/result describe the path that just ended (ignored when need_new is set).
+    auto advance = [&](bool path_done, v3 result) {
+        while (active && (need_new || path_done || bounce >= limit)) {
+            if (!need_new) {
+                // rayColor returned: compute.wgsl:121
+                frame_sum = frame_sum + (path_done ? result : color);
+                path_done = false;
+                sample++;
+                if (sample == P.spp) {
+                    // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                    const v3 mean = frame_sum / fspp;
+                    acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                    frame_sum = V3(0.0f, 0.0f, 0.0f);
+                    sample = 0;
+                    frame++;
+                    if (frame == P.n_frames) { active = false; break; }
+                }
+            }
+            if (sample == 0) {
+                // compute.wgsl:85
+                const uint32_t time = P.time0 + frame * P.stride;
+                sx = x; sy = y; sz = x + time; sw = y + time;
+            }
+            // compute.wgsl:113-119, 131-136
+            const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+            const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+            const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
+            cur.o = P.fr.origin;
+            cur.d = (ploc + smp) - P.fr.origin;
+            initial_d = cur.d;
+            color = V3(1.0f, 1.0f, 1.0f);
+            seed = pt_hybrid_taus(sx, sy, sz, sw);
+            bounce = 0;
+            limit = P.depth;
+            need_new = false;
+            want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
+            cn.paths++;
+        }
+    };
+
+    advance(false, V3(0.0f, 0.0f, 0.0f));
+
+    while (active) {
+        cn.rays++;
+        const Closest c = hit_scene<STATS>(sc, cur, stack, cn);
+        const HitRecord h = make_record(sc, cur, c);
+        if (want_aov) {
+            P.aov_prim[pix] = h.prim;
+            P.aov_t[pix] = h.hit ? h.t : 0.0f;
+            want_aov = false;
+        }
+
+        bool path_done = false;
+        v3 result = V3(0.0f, 0.0f, 0.0f);
+        if (!h.hit) {
+            // compute.wgsl:140-143
+            if (STATS) cn.sky++;
+            result = color * sky_lookup(sc, cur.d);
+            path_done = true;
+        } else {
+            if (STATS) cn.bounces++;
+            const v3 dir = normalize3(cur.d);
+            v3 bdir = dir;
+            const uint32_t m = material_u32(h.material);
+            if (m == 1u) {
+                bdir = reflect_dir(dir, h.normal);
+            } else if (m == 2u) {
+                const float ri = h.front ? (1.0f / 1.5f) : 1.5f;
+                const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
+                const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
+                const bool cannot = ri * sin_t > 1.0f;
+                if (cannot || reflectance(cos_t, ri) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
+                else bdir = refract_dir(dir, h.normal, ri);
+            } else if (m == 3u) {
+                const float dn = dot3(initial_d, h.normal);
+                if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
+                    result = h.att;
+                    path_done = true;
+                }
+                limit++;  // correction, compute.wgsl:193
+            } else {
+                bdir = scatter_dir(dir, h.normal, seed);
+            }
+            if (m <= 1u && dot3(bdir, h.normal) <= 0.0f) {
+                // compute.wgsl:151-153, 161-163: absorbed ray still sees the sky along the incoming ray
+                if (STATS) cn.sky++;
+                result = (color * h.att) * sky_lookup(sc, cur.d);
+                path_done = true;
+            }
+            if (!path_done) {
+                if (m != 3u) color = color * h.att;
+                cur.o = h.p;
+                cur.d = bdir;
+                bounce++;
+            }
+        }
+        advance(path_done, result);
+    }
+
+    if ((x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0) P.accum[pix] = acc;
+
+    // one atomic per wave and counter
+    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces};
+    const int ncount = STATS ? PT_NUM_COUNTERS : 2;
+    for (int k = 0; k < ncount; k++) {
+        const uint32_t s = wave_sum(vals[k]);
+        if (lane == 0 && s) atomicAdd(&P.counters[k], (unsigned long long)s);
+    }
+}
+
+// ---- explicit ray queries ---------------------------------------------------------------
+template <bool OVERFLOW>
+__global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
+{
+    const uint32_t tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * PT_BLOCK + tid;
+    __shared__ uint32_t smem[PT_LDS_STACK * PT_BLOCK];
+    Stack<OVERFLOW> stack{&smem[tid], nullptr, 0};
+    if (OVERFLOW) {
+        stack.spill = Q.gstack + i;
+        stack.pitch = (size_t)gridDim.x * PT_BLOCK;
+    }
+    if (i >= Q.n) return;
+    Ray r;
+    r.o = V3(Q.origins[3 * i], Q.origins[3 * i + 1], Q.origins[3 * i + 2]);
+    r.d = V3(Q.dirs[3 * i], Q.dirs[3 * i + 1], Q.dirs[3 * i + 2]);
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    const Closest c = hit_scene<false>(Q.sc, r, stack, cn);
+    const HitRecord h = make_record(Q.sc, r, c);
+    if (Q.prim) Q.prim[i] = h.prim;
+    if (Q.t) Q.t[i] = h.t;
+    if (Q.p) { Q.p[3 * i] = h.p.x; Q.p[3 * i + 1] = h.p.y; Q.p[3 * i + 2] = h.p.z; }
+    if (Q.normal) { Q.normal[3 * i] = h.normal.x; Q.normal[3 * i + 1] = h.normal.y; Q.normal[3 * i + 2] = h.normal.z; }
+    if (Q.front) Q.front[i] = h.front ? 1u : 0u;
+}
+
+// ---- accumulation read-out ----------------------------------------------------------------
+// mean = sum / frames (frames kept in .w); mode 1 also clamps and quantises like an
+// rgba8unorm store: round(clamp(c,0,1)*255).
+__global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, uint32_t n, float4 *out_f, uint32_t *out_u8, int mode)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = accum[i];
+    float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.w > 0.0f) m = make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f);
+    if (mode == 0) {
+        out_f[i] = m;
+    } else {
+        auto q = [](float c) -> uint32_t {
+            c = pt_min(pt_max(c, 0.0f), 1.0f);  // NaN -> 0
+            return (uint32_t)pt_rint(c * 255.0f);
+        };
+        out_u8[i] = q(m.x) | (q(m.y) << 8) | (q(m.z) << 16) | (q(m.w) << 24);
+    }
+}
+
+// ---- equirectangular -> cube map: shaders/equirectangular.wgsl:12-81 -----------------------
+__global__ __launch_bounds__(256) void equirect_kernel(const float4 *src, uint32_t src_w, uint32_t src_h, float4 *dst, uint32_t size)
+{
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+    const uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    const uint32_t f = blockIdx.z;
+    if (x >= size || y >= size) return;
+    v3 fw, up, rt;
+    switch (f) {  // forward, up, right per face (equirectangular.wgsl:25-62)
+    case 0: fw = V3(1, 0, 0); up = V3(0, 1, 0); rt = V3(0, 0, -1); break;
+    case 1: fw = V3(-1, 0, 0); up = V3(0, 1, 0); rt = V3(0, 0, 1); break;
+    case 2: fw = V3(0, -1, 0); up = V3(0, 0, 1); rt = V3(1, 0, 0); break;
+    case 3: fw = V3(0, 1, 0); up = V3(0, 0, -1); rt = V3(1, 0, 0); break;
+    case 4: fw = V3(0, 0, 1); up = V3(0, 1, 0); rt = V3(1, 0, 0); break;
+    default: fw = V3(0, 0, -1); up = V3(0, 1, 0); rt = V3(-1, 0, 0); break;
+    }
+    const float fsz = (float)size;
+    const float cu = pt_fma((float)x / fsz, 2.0f, -1.0f), cv = pt_fma((float)y / fsz, 2.0f, -1.0f);
+    const v3 sph = normalize3(v3_fma(cv, up, v3_fma(cu, rt, fw)));
+    const float eu = pt_fma(pt_atan2(sph.z, sph.x), 0.1591f, 0.5f);
+    const float ev = pt_fma(pt_asin(sph.y), 0.3183f, 0.5f);
+    const int32_t ix = (int32_t)(eu * (float)src_w), iy = (int32_t)(ev * (float)src_h);
+    float4 texel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (ix >= 0 && iy >= 0 && (uint32_t)ix < src_w && (uint32_t)iy < src_h) texel = src[(size_t)iy * src_w + (uint32_t)ix];
+    dst[((size_t)f * size + y) * size + x] = texel;
+}
+
+}  // namespace
+
+static size_t spill_entries(uint32_t stack_depth) { return stack_depth > PT_LDS_STACK ? stack_depth - PT_LDS_STACK : 0; }
+
+size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth)
+{
+    const size_t bx = (width + 15u) / 16u, by = (height + 15u) / 16u;
+    return bx * by * PT_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
+}
+
+hipError_t pt_launch_trace(const PtTraceParams &p, uint32_t stack_depth, bool detailed_stats, hipStream_t stream)
+{
+    const dim3 grid((p.width + 15u) / 16u, (p.height + 15u) / 16u, 1), block(PT_BLOCK, 1, 1);
+    if (grid.x == 0 || grid.y == 0) return hipSuccess;
+    const bool overflow = spill_entries(stack_depth) > 0;
+    if (overflow && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
+#define PT_LAUNCH(ST, OV) hipLaunchKernelGGL((trace_kernel<ST, OV>), grid, block, 0, stream, p)
+    if (overflow) {
+        if (detailed_stats) PT_LAUNCH(true, true); else PT_LAUNCH(false, true);
+    } else {
+        if (detailed_stats) PT_LAUNCH(true, false); else PT_LAUNCH(false, false);
+    }
+#undef PT_LAUNCH
+    return hipGetLastError();
+}
+
+size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth)
+{
+    const size_t blocks = ((size_t)n + PT_BLOCK - 1) / PT_BLOCK;
+    return blocks * PT_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
+}
+
+hipError_t pt_launch_ray_query(const PtRayQuery &q, uint32_t stack_depth, hipStream_t stream)
+{
+    if (q.n == 0) return hipSuccess;
+    const dim3 grid((q.n + PT_BLOCK - 1) / PT_BLOCK, 1, 1), block(PT_BLOCK, 1, 1);
+    const bool overflow = spill_entries(stack_depth) > 0;
+    if (overflow && (!q.gstack || q.gstack_cap < stack_depth)) return hipErrorInvalidValue;
+    if (overflow) hipLaunchKernelGGL((ray_query_kernel<true>), grid, block, 0, stream, q);
+    else hipLaunchKernelGGL((ray_query_kernel<false>), grid, block, 0, stream, q);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_resolve(const float4 *accum, uint32_t n_pixels, float4 *out_f, uint32_t *out_u8, int mode, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, accum, n_pixels, out_f, out_u8, mode);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_equirect(const float4 *src, uint32_t src_w, uint32_t src_h, float4 *dst, uint32_t size, hipStream_t stream)
+{
+    if (size == 0) return hipSuccess;
+    hipLaunchKernelGGL(equirect_kernel, dim3((size + 15u) / 16u, (size + 15u) / 16u, 6), dim3(256), 0, stream, src, src_w, src_h, dst, size);
+    return hipGetLastError();
+}

@@ -1,0 +1,174 @@
+// pt_math.h -- the one floating-point evaluation every part of the renderer uses.
+//
+// WGSL leaves fusing and the accuracy of sin/cos/tan/pow/normalize to the implementation,
+// and the shader's fract(sin(x)*43758.5453) hash (shaders/include/utils.wgsl:3-5) turns one
+// ulp of difference into an unrelated random number.  Results are therefore reproducible
+// only against one fixed evaluation, which this header pins down for host and device:
+//   * IEEE-754 binary32, round-to-nearest-even, subnormals kept, no fast-math;
+//   * a fused multiply-add exactly where pt_fma is written and nowhere else (the translation
+//     units are built with -ffp-contract=off);
+//   * correctly rounded '/' and sqrt; min/max = minNum/maxNum;
+//   * sin/cos by a 3-step fused Cody-Waite reduction and fixed minimax polynomials.
+// Host code (camera frame, scene set-up) and gfx950 kernels compile this same text.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_HD __host__ __device__ __forceinline__
+
+struct v3 {
+    float x, y, z;
+};
+
+PT_HD float pt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_HD float pt_min(float a, float b) { return __builtin_fminf(a, b); }
+PT_HD float pt_max(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_HD float pt_abs(float a) { return __builtin_fabsf(a); }
+PT_HD float pt_sqrt(float a) { return __builtin_sqrtf(a); }
+PT_HD float pt_floor(float a) { return __builtin_floorf(a); }
+PT_HD float pt_rint(float a) { return __builtin_rintf(a); }
+
+PT_HD v3 V3(float x, float y, float z) { return v3{x, y, z}; }
+PT_HD v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+PT_HD v3 operator/(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+PT_HD v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+// s*a + c, one rounding per component
+PT_HD v3 v3_fma(float s, v3 a, v3 c) { return V3(pt_fma(s, a.x, c.x), pt_fma(s, a.y, c.y), pt_fma(s, a.z, c.z)); }
+PT_HD float dot3(v3 a, v3 b) { return pt_fma(a.z, b.z, pt_fma(a.y, b.y, a.x * b.x)); }
+PT_HD v3 cross3(v3 a, v3 b)
+{
+    return V3(pt_fma(a.y, b.z, -(a.z * b.y)), pt_fma(a.z, b.x, -(a.x * b.z)), pt_fma(a.x, b.y, -(a.y * b.x)));
+}
+PT_HD v3 normalize3(v3 a)
+{
+    const float inv = 1.0f / pt_sqrt(dot3(a, a));
+    return a * inv;
+}
+
+// sin(x) and cos(x).  k = nearest integer to x*2/pi; r = x - k*pi/2 in three fused steps
+// (pi/2 split hi/mid/lo); polynomials on [-pi/4, pi/4]; quadrant from k mod 4.
+PT_HD void pt_sincos(float x, float &s_out, float &c_out)
+{
+    const float k = pt_rint(x * 0.63661977236758134f);
+    float r = pt_fma(-k, 1.57079637050628662f, x);
+    r = pt_fma(-k, -4.37113882867379e-08f, r);
+    r = pt_fma(-k, -1.71512451000588e-15f, r);
+    const float s = r * r;
+    float ps = pt_fma(s, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = pt_fma(s, ps, -1.6666654611e-1f);
+    ps = pt_fma(s * r, ps, r);
+    float pc = pt_fma(s, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = pt_fma(s, pc, 4.166664568298827e-2f);
+    pc = pt_fma(s * s, pc, pt_fma(-0.5f, s, 1.0f));
+    const int q = (k >= -2147483648.0f && k < 2147483648.0f) ? (int)k : 0;
+    float sv = (q & 1) ? pc : ps;
+    float cv = (q & 1) ? ps : pc;
+    if (q & 2) sv = -sv;
+    if ((q + 1) & 2) cv = -cv;
+    s_out = sv;
+    c_out = cv;
+}
+PT_HD float pt_sin(float x)
+{
+    float s, c;
+    pt_sincos(x, s, c);
+    return s;
+}
+PT_HD float pt_tan(float x)
+{
+    float s, c;
+    pt_sincos(x, s, c);
+    return s / c;
+}
+
+// atan on [0,1] (odd polynomial), octant fix-up; used only by the equirect->cube kernel.
+PT_HD float pt_atan_unit(float a)
+{
+    const float s = a * a;
+    float p = pt_fma(s, 0.00282363896258175373077393f, -0.0159569028764963150024414f);
+    p = pt_fma(s, p, 0.0425049886107444763183594f);
+    p = pt_fma(s, p, -0.0748900920152664184570312f);
+    p = pt_fma(s, p, 0.106347933411598205566406f);
+    p = pt_fma(s, p, -0.142027363181114196777344f);
+    p = pt_fma(s, p, 0.199926957488059997558594f);
+    p = pt_fma(s, p, -0.333331018686294555664062f);
+    return pt_fma(s * a, p, a);
+}
+PT_HD float pt_atan2(float y, float x)
+{
+    const float ax = pt_abs(x), ay = pt_abs(y);
+    const float mx = pt_max(ax, ay), mn = pt_min(ax, ay);
+    float a = (mx == 0.0f) ? 0.0f : pt_atan_unit(mn / mx);
+    if (ay > ax) a = 1.57079637050628662f - a;
+    if (x < 0.0f) a = 3.14159274101257324f - a;
+    return (y < 0.0f) ? -a : a;
+}
+PT_HD float pt_asin(float x) { return pt_atan2(x, pt_sqrt((1.0f - x) * (1.0f + x))); }
+
+PT_HD float pt_fract(float x) { return x - pt_floor(x); }
+
+// rand(): shaders/include/utils.wgsl:3-5
+PT_HD float pt_hash_rand(float sx, float sy)
+{
+    const float d = pt_fma(sy, 78.233f, sx * 12.9898f);
+    return pt_fract(pt_sin(d) * 43758.5453f);
+}
+
+// randomUnit(): shaders/include/utils.wgsl:15-22
+PT_HD v3 pt_random_unit(float sx, float sy)
+{
+    const float z = pt_fma(pt_hash_rand(sx, sy), 2.0f, -1.0f);
+    const float a = (pt_hash_rand(sx * z, sy * z) * 2.0f) * 3.14159274101257324f;
+    const float r = pt_sqrt(pt_fma(-z, z, 1.0f));
+    float sa, ca;
+    pt_sincos(a, sa, ca);
+    return V3(r * ca, r * sa, z);
+}
+
+// hybridTaus(): shaders/include/utils.wgsl:33-58.  Advances st, returns the value in [0,1].
+PT_HD uint32_t pt_tau_step(uint32_t z, int s1, int s2, int s3, uint32_t m)
+{
+    const uint32_t b = ((z << s1) ^ z) >> s2;
+    return ((z & m) << s3) ^ b;
+}
+PT_HD float pt_hybrid_taus(uint32_t &sx, uint32_t &sy, uint32_t &sz, uint32_t &sw)
+{
+    sx = pt_tau_step(sx, 13, 19, 12, 4294967294u);
+    sy = pt_tau_step(sy, 2, 25, 4, 4294967288u);
+    sz = pt_tau_step(sz, 3, 11, 17, 4294967280u);
+    sw = 1664525u * sw + 1013904223u;
+    return 2.3283064365387e-10f * (float)(sx ^ sy ^ sz ^ sw);
+}
+
+// Camera frame shared by every pixel: shaders/compute.wgsl:93-107.
+struct pt_frame {
+    v3 origin, pixel00, du, dv;
+};
+PT_HD pt_frame pt_camera_frame(const float cam[16], uint32_t W, uint32_t H)
+{
+    const v3 origin = V3(cam[0], cam[1], cam[2]);
+    const float focal = cam[3];
+    const v3 forward = V3(cam[4], cam[5], cam[6]);
+    const float vfov = cam[7];
+    const v3 right = V3(cam[8], cam[9], cam[10]);
+    const v3 up = V3(cam[12], cam[13], cam[14]);
+    const float fw = (float)W, fh = (float)H;
+    const float aspect = fw / fh;
+    const float theta = vfov * 0.017453292519943295f;
+    const float h = pt_tan(theta / 2.0f);
+    const float vph = (2.0f * h) * focal;
+    const float vpw = aspect * vph;
+    const v3 U = right * vpw;
+    const v3 Vv = up * (-vph);
+    pt_frame f;
+    f.du = U / fw;
+    f.dv = Vv / fh;
+    f.origin = origin;
+    const v3 ul = v3_fma(focal, forward, origin) - (U + Vv) * 0.5f;
+    f.pixel00 = ul + (f.du + f.dv) * 0.5f;
+    return f;
+}

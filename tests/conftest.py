@@ -1,0 +1,45 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import _pkgload  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """The .so files are built by __graft_entry__.build() and travel with the tree; this only
+    covers a fresh checkout on a machine with the toolchain."""
+    lib = os.path.join(ROOT, "path-tracer_amd", "libptrt.so")
+    ora = os.path.join(ROOT, "oracle", "libpt_oracle.so")
+    if not os.path.exists(ora):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "path-tracer_amd", "csrc")])
+
+
+@pytest.fixture(scope="session")
+def pt():
+    _ensure_built()
+    return _pkgload.load()
+
+
+@pytest.fixture(scope="session")
+def scenes(pt):
+    import importlib
+    return importlib.import_module("path_tracer_amd.scenes")
+
+
+@pytest.fixture(scope="session")
+def po(pt):
+    from oracle import pt_oracle
+    pt_oracle.lib()
+    return pt_oracle
