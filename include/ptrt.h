@@ -58,6 +58,7 @@ typedef struct pt_stats_t {
     uint64_t sphere_tests;  /* hitSphere calls              (PT_FLAG_DETAILED_STATS only) */
     uint64_t sky_lookups;   /* getBackgroundColor calls     (PT_FLAG_DETAILED_STATS only) */
     uint64_t bounces;       /* material switch executions   (PT_FLAG_DETAILED_STATS only) */
+    uint64_t sphere_accept; /* sphere hits that replaced the record (PT_FLAG_DETAILED_STATS only) */
     uint64_t frames;        /* dispatch-equivalents accumulated since the last pt_reset */
     uint64_t bvh_depth;     /* deepest leaf of the uploaded BVH = traversal stack bound */
 } pt_stats_t;

@@ -98,6 +98,7 @@ typedef struct {
     uint64_t sphere_tests;  /* hitSphere calls */
     uint64_t sky_lookups;   /* getBackgroundColor calls */
     uint64_t bounces;       /* material switch executions */
+    uint64_t sphere_accept; /* sphere hits that replaced the record */
     uint64_t overflow15;    /* rays whose stack would exceed the shader's 15 */
     uint64_t max_stack;     /* deepest stack seen */
 } pto_stats;
@@ -302,7 +303,7 @@ static hit_t hit_scene(ctx_t *cx, ray_t ray)
     for (uint32_t i = 0; i < nsph; i++) {
         hit_t h = hit_sphere(cx, ray, &sc->spheres->s[i], i);
         if (!h.hit) continue;
-        if (!rec.hit || h.t < rec.t) rec = h;
+        if (!rec.hit || h.t < rec.t) { rec = h; cx->st.sphere_accept++; }
     }
     /* the shader reads bvhNodes[0] unconditionally; an empty BVH is skipped here */
     if (sc->n_nodes == 0) return rec;
@@ -522,7 +523,7 @@ static void stats_add(pto_stats *d, const pto_stats *s)
 {
     d->rays += s->rays; d->paths += s->paths; d->interior += s->interior; d->tri_tests += s->tri_tests;
     d->tri_accept += s->tri_accept; d->sphere_tests += s->sphere_tests; d->sky_lookups += s->sky_lookups;
-    d->bounces += s->bounces; d->overflow15 += s->overflow15;
+    d->bounces += s->bounces; d->sphere_accept += s->sphere_accept; d->overflow15 += s->overflow15;
     if (s->max_stack > d->max_stack) d->max_stack = s->max_stack;
 }
 

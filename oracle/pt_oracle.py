@@ -28,7 +28,7 @@ class SceneStruct(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "interior", "tri_tests", "tri_accept", "sphere_tests",
-                                          "sky_lookups", "bounces", "overflow15", "max_stack")]
+                                          "sky_lookups", "bounces", "sphere_accept", "overflow15", "max_stack")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

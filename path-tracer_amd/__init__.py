@@ -52,7 +52,7 @@ class PtError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "interior", "tri_tests", "tri_accept", "sphere_tests",
-                                          "sky_lookups", "bounces", "frames", "bvh_depth")]
+                                          "sky_lookups", "bounces", "sphere_accept", "frames", "bvh_depth")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

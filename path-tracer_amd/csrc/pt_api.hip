@@ -528,6 +528,7 @@ int pt_stats(pt_ctx *ctx, pt_stats_t *out)
     out->sphere_tests = c[5];
     out->sky_lookups = c[6];
     out->bounces = c[7];
+    out->sphere_accept = c[8];
     out->frames = ctx->frames;
     out->bvh_depth = ctx->bvh_depth;
     return PT_OK;

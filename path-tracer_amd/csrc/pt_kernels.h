@@ -9,7 +9,7 @@
 
 #define PT_BLOCK 256        // 4 waves; each wave owns an 8x8 pixel tile of a 16x16 block tile
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (24 KiB per block)
-#define PT_NUM_COUNTERS 8   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces
+#define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
     // spheres: 2 float4 each {center, radius} {albedo, material}

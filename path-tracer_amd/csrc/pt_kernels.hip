@@ -45,7 +45,7 @@ struct Stack {
 };
 
 struct Counters {
-    uint32_t rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces;
+    uint32_t rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept;
 };
 
 // Closest-hit record kept in registers during traversal; the full record (point, normal,
@@ -123,6 +123,7 @@ __device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray 
                 rec.hit = true;
                 rec.t = root;
                 rec.index = i;
+                if (STATS) cn.sphere_accept++;
             }
         }
     }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
         stack.pitch = (size_t)gridDim.x * gridDim.y * PT_BLOCK;
     }
 
-    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool active = (x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0;
 
     const PtDeviceScene &sc = P.sc;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
     if ((x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0) P.accum[pix] = acc;
 
     // one atomic per wave and counter
-    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces};
+    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 2;
     for (int k = 0; k < ncount; k++) {
         const uint32_t s = wave_sum(vals[k]);
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     Ray r;
     r.o = V3(Q.origins[3 * i], Q.origins[3 * i + 1], Q.origins[3 * i + 2]);
     r.d = V3(Q.dirs[3 * i], Q.dirs[3 * i + 1], Q.dirs[3 * i + 2]);
-    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const Closest c = hit_scene<false>(Q.sc, r, stack, cn);
     const HitRecord h = make_record(Q.sc, r, c);
     if (Q.prim) Q.prim[i] = h.prim;

@@ -46,61 +46,68 @@ def three_balls(camera: Camera | None = None) -> Scene:
     return Scene(spheres, np.zeros(0, TRIANGLE_DTYPE), cam)
 
 
-def blob_mesh(segments: int = 187, rings: int = 186, center=(1.0, 0.5, -1.0), radius: float = 1.0,
-              yaw: float = 0.0) -> np.ndarray:
-    """Closed displaced UV sphere standing in for the Stanford bunny: 2*segments*(rings-1)
-    triangles (69 190 at the defaults), smooth area-weighted vertex normals, O(1) scale."""
-    th = np.linspace(0.0, np.pi, rings + 1)[:, None]            # polar
-    ph = (np.arange(segments) * (2.0 * np.pi / segments))[None, :]
-    r = 0.72 + 0.14 * np.sin(3 * th) * np.sin(4 * ph + 0.5) + 0.08 * np.sin(7 * th + 1.0) * np.cos(5 * ph) \
-        + 0.05 * np.cos(11 * ph + 2 * th) * np.sin(th) ** 2
-    r = r * radius
-    x, y, z = r * np.sin(th) * np.cos(ph), r * np.cos(th), r * np.sin(th) * np.sin(ph)
+def blob_mesh(n: int = 76, center=(0.0, 0.5, -1.0), radius: float = 1.0, yaw: float = 0.0) -> np.ndarray:
+    """Closed displaced cube-sphere standing in for the Stanford bunny: 12*n*n triangles of
+    similar size (69 312 at n = 76), smooth area-weighted vertex normals, O(1) scale."""
+    g = np.linspace(-1.0, 1.0, n + 1)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    one = np.ones_like(u)
+    # six faces, each oriented so that (du x dv) points outwards
+    faces_uv = [np.stack([one, u, v], -1), np.stack([-one, v, u], -1), np.stack([v, one, u], -1),
+                np.stack([u, -one, v], -1), np.stack([u, v, one], -1), np.stack([v, u, -one], -1)]
+    verts, tris_idx, base = [], [], 0
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    for fv in faces_uv:
+        verts.append(fv.reshape(-1, 3))
+        a = base + ii * (n + 1) + jj
+        b, c, d = a + (n + 1), a + 1, a + (n + 1) + 1
+        tris_idx.append(np.stack([a, b, c], -1).reshape(-1, 3))
+        tris_idx.append(np.stack([c, b, d], -1).reshape(-1, 3))
+        base += (n + 1) * (n + 1)
+    V = np.concatenate(verts)
+    F = np.concatenate(tris_idx)
+    # weld the shared edge/corner vertices of neighbouring faces
+    key = np.round(V * n).astype(np.int64)
+    _, first, inverse = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    V, F = V[first], inverse.reshape(-1)[F]
+    D = V / np.linalg.norm(V, axis=1, keepdims=True)
+    th, ph = np.arccos(np.clip(D[:, 1], -1, 1)), np.arctan2(D[:, 2], D[:, 0])
+    r = 0.72 + 0.14 * np.sin(3 * th) * np.sin(4 * ph + 0.5) * np.sin(th) ** 2 + 0.08 * np.sin(7 * th + 1.0) * np.cos(5 * ph) * np.sin(th) ** 2 \
+        + 0.05 * np.cos(6 * D[:, 0] + 2.0) * np.cos(5 * D[:, 1]) * np.cos(4 * D[:, 2] + 1.0)
+    P = D * (r * radius)[:, None]
     cy, sy = np.cos(yaw), np.sin(yaw)
-    x, z = cy * x + sy * z, -sy * x + cy * z
-    P = np.stack([x, y, z], -1)                                  # (rings+1, segments, 3)
-    P[0, :, :] = P[0, :1, :]
-    P[-1, :, :] = P[-1, :1, :]
-    idx = np.arange((rings + 1) * segments).reshape(rings + 1, segments)
-    idx[0, :] = idx[0, 0]
-    idx[-1, :] = idx[-1, 0]
-    a, b = idx[:-1, :], np.roll(idx[:-1, :], -1, axis=1)
-    c, d = idx[1:, :], np.roll(idx[1:, :], -1, axis=1)
-    t1 = np.stack([a, c, b], -1)[1:]                              # skip degenerate at the north pole
-    t2 = np.stack([b, c, d], -1)[:-1]                             # skip degenerate at the south pole
-    faces = np.concatenate([t1.reshape(-1, 3), t2.reshape(-1, 3)])
-    V = P.reshape(-1, 3)
-    fn = np.cross(V[faces[:, 1]] - V[faces[:, 0]], V[faces[:, 2]] - V[faces[:, 0]])
-    N = np.zeros_like(V)
+    P = np.stack([cy * P[:, 0] + sy * P[:, 2], P[:, 1], -sy * P[:, 0] + cy * P[:, 2]], -1)
+    fn = np.cross(P[F[:, 1]] - P[F[:, 0]], P[F[:, 2]] - P[F[:, 0]])
+    N = np.zeros_like(P)
     for k in range(3):
-        np.add.at(N, faces[:, k], fn)
+        np.add.at(N, F[:, k], fn)
     ln = np.linalg.norm(N, axis=1, keepdims=True)
     N = np.where(ln > 0, N / np.maximum(ln, 1e-30), np.array([0.0, 1.0, 0.0]))
-    V = V + np.asarray(center, np.float64)
-    tris = np.zeros(len(faces), TRIANGLE_DTYPE)
+    P = P + np.asarray(center, np.float64)
+    tris = np.zeros(len(F), TRIANGLE_DTYPE)
     for k, (pn, nn) in enumerate((("a", "na"), ("b", "nb"), ("c", "nc"))):
-        tris[pn] = V[faces[:, k]].astype(np.float32)
-        tris[nn] = N[faces[:, k]].astype(np.float32)
+        tris[pn] = P[F[:, k]].astype(np.float32)
+        tris[nn] = N[F[:, k]].astype(np.float32)
     tris["albedo"] = 1.0
     tris["material"] = 0
     return tris
 
 
-def bunny(camera: Camera | None = None, segments: int = 187, rings: int = 186) -> Scene:
-    """Mesh (~69k triangles) on a large ground sphere, default camera."""
-    tris = blob_mesh(segments, rings)
+def bunny(camera: Camera | None = None, n: int = 76) -> Scene:
+    """Mesh (~69k triangles at n = 76) on a large ground sphere, default camera."""
+    tris = blob_mesh(n)
     spheres = [Sphere((0.0, -100.5, -1.0), 100.0, (0.8, 0.8, 0.0), Material.Diffuse)]
     return Scene(spheres, tris, camera or default_camera())
 
 
-def instanced_field(grid: int = 12, pitch: float = 2.5, segments: int = 187, rings: int = 186) -> Scene:
+def instanced_field(grid: int = 12, pitch: float = 2.5, n: int = 76) -> Scene:
     """grid x grid copies of the mesh flattened into one triangle list (12x12 -> ~10.0 M)."""
     rng = np.random.RandomState(2)
     parts = []
     for i in range(grid):
         for j in range(grid):
             cx, cz = (i - (grid - 1) / 2) * pitch + 1.0, -1.0 - j * pitch
-            parts.append(blob_mesh(segments, rings, (cx, 0.5, cz), 1.0, float(rng.uniform(0, 2 * np.pi))))
+            parts.append(blob_mesh(n, (cx, 0.5, cz), 1.0, float(rng.uniform(0, 2 * np.pi))))
     spheres = [Sphere((0.0, -100.5, -1.0), 100.0, (0.8, 0.8, 0.0), Material.Diffuse)]
     cam = Camera.from_yaw_pitch((1.0, 6.0, 8.0), -90.0, -25.0, 1.0, 75.0)
     return Scene(spheres, np.concatenate(parts), cam)

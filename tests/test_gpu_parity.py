@@ -53,7 +53,7 @@ def test_image_parity_small(pt, po, scenes, name, w, h, spp, depth):
 
 def test_mesh_parity_blob(pt, po, scenes):
     """Deep midpoint-split tree (stack spills past the LDS part) + ground sphere."""
-    scene = scenes.bunny(segments=61, rings=60)
+    scene = scenes.bunny(n=24)
     sky = scenes.sky_cube_direct(32)
     st = pt.Settings(1, 8, 1e-4, 1000.0)
     r, acc, prim, tt, rays = _both(pt, po, scene, 192, 108, st, sky, [7, 8])
