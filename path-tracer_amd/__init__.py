@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptrt.so")
+LIB_PATH = os.environ.get("PTRT_LIB", os.path.join(_HERE, "libptrt.so"))  # PTRT_LIB: diagnostic builds only
 
 PT_FLAG_REFERENCE_DISPATCH = 1
 PT_FLAG_AOV = 2

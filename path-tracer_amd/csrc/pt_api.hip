@@ -11,8 +11,10 @@
 //                                   BVH's index permutation, so a leaf's triangles are contiguous
 //   tri_nrm   3 float4 per slot     vertex normals, touched once per closest hit
 //   sky       6*size*size float4    cube faces +X,-X,+Y,-Y,+Z,-Z
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -51,6 +53,12 @@ struct pt_ctx {
     uint32_t *gstack = nullptr;
     size_t gstack_bytes = 0;
     uint32_t gstack_cap = 0;
+
+    float4 *partial = nullptr;  // per-chunk partial sums of multi-frame launches
+    size_t partial_bytes = 0;
+    uint32_t chunk_frames = 0;  // 0 = choose per call
+    uint32_t *tile_cost = nullptr, *tile_order = nullptr;  // load balancing: see order_kernel
+    bool order_valid = false;
 
     void *scratch = nullptr;  // read-back staging for resolve
     size_t scratch_bytes = 0;
@@ -193,6 +201,10 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_NUM_COUNTERS * sizeof(unsigned long long)), "counters");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 2 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
+    const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((height + 15u) / 16u);
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_cost, n_tiles * sizeof(uint32_t)), "tile cost");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_order, n_tiles * sizeof(uint32_t)), "tile order");
+    if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_t, 0, n * sizeof(float)), "clear");
@@ -220,6 +232,9 @@ void pt_destroy(pt_ctx *ctx)
     free_mesh(ctx);
     dev_free(ctx->sky);
     dev_free(ctx->gstack);
+    dev_free(ctx->partial);
+    dev_free(ctx->tile_cost);
+    dev_free(ctx->tile_order);
     dev_free(ctx->scratch);
     delete ctx;
 }
@@ -413,9 +428,6 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "pt_render: no camera set");
     if (n_frames == 0) return PT_OK;
     if (ctx->settings.samples_per_pixel == 0) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel is 0 (the shader would divide by zero)");
-    // per-lane ray counter is 32 bits
-    const uint64_t worst = (uint64_t)n_frames * ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);
-    if (worst >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render: n_frames*spp*depth too large for one launch; split the call");
 
     PtTraceParams p{};
     p.sc = device_scene(ctx);
@@ -430,9 +442,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     p.spp = ctx->settings.samples_per_pixel;
     p.depth = ctx->settings.depth;
-    p.time0 = time0;
     p.stride = stride;
-    p.n_frames = n_frames;
     p.accum = ctx->accum;
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
     p.aov_t = ctx->aov_t;
@@ -444,8 +454,48 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     p.gstack = ctx->gstack;
     p.gstack_cap = gs ? ctx->bvh_depth : 0;
-    PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, ctx->stream));
-    ctx->frames += n_frames;
+    p.order = ctx->tile_order;
+    p.cost = ctx->tile_cost;
+    if (getenv("PTRT_NO_ORDER")) p.order = nullptr, p.cost = nullptr;  // tuning aid
+
+    // Frames per work item: enough items per tile to balance the chip (about 8), few enough
+    // that a lane's next path can start while its neighbours finish theirs (up to 32).
+    uint32_t chunk = ctx->chunk_frames ? ctx->chunk_frames : std::min(32u, std::max(4u, (n_frames + 7u) / 8u));
+    if (const char *env = getenv("PTRT_CHUNK_FRAMES")) chunk = (uint32_t)atoi(env);  // tuning aid
+    // One launch covers at most max_chunks work items per tile so that the partial sums stay
+    // under ~4 GiB, and few enough frames that the per-lane 32-bit ray counter cannot wrap.
+    const size_t image_bytes = (size_t)ctx->width * ctx->height * sizeof(float4);
+    const uint32_t max_chunks = (uint32_t)std::max<size_t>(8, std::min<size_t>(256, ((size_t)4 << 30) / image_bytes));
+    const uint64_t per_frame = (uint64_t)ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);
+    if (per_frame >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render: spp*depth too large");
+    const uint32_t max_frames = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / per_frame, 0x7FFFFFFFull);
+    if (max_frames == 0) return fail(ctx, PT_ERR_LIMIT, "pt_render: spp*depth too large");
+
+    uint32_t done = 0;
+    while (done < n_frames) {
+        uint32_t batch = n_frames - done;
+        if (chunk && (uint64_t)chunk * max_chunks < batch) batch = chunk * max_chunks;
+        batch = std::min(batch, max_frames);
+        p.time0 = time0 + done * stride;
+        p.n_frames = batch;
+        p.chunk_frames = chunk;
+        const uint32_t n_chunks = pt_trace_num_chunks(batch, chunk, ctx->bvh_depth);
+        if (n_chunks > 1) {
+            const size_t need = (size_t)n_chunks * image_bytes;
+            if (need > ctx->partial_bytes) {
+                PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                dev_free(ctx->partial);
+                ctx->partial_bytes = 0;
+                PT_HIP(ctx, hipMalloc((void **)&ctx->partial, need));
+                ctx->partial_bytes = need;
+            }
+        }
+        p.partial = ctx->partial;
+        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, &ctx->order_valid, ctx->stream));
+        done += batch;
+        ctx->frames += batch;
+        p.aov_prim = nullptr;  // the AOV belongs to the first frame of the call
+    }
     return PT_OK;
 }
 

@@ -36,6 +36,13 @@ struct PtTraceParams {
     uint32_t cols, rows;     // pixels actually rendered (smaller under PT_FLAG_REFERENCE_DISPATCH)
     uint32_t spp, depth;
     uint32_t time0, stride, n_frames;
+    uint32_t chunk_frames;   // frames per work item; items of one tile write separate partial sums
+    uint32_t n_chunks;       // filled in by pt_launch_trace
+    uint32_t tiles_x, tiles_y, n_tiles;  // filled in by pt_launch_trace
+    uint32_t chunk_base, launch_chunks;  // filled in by pt_launch_trace (chunks covered by one launch)
+    const uint32_t *order;   // optional: n_tiles entries, rewritten after each launch (costliest tile first)
+    uint32_t *cost;          // optional: n_tiles wave-time sums, zero before the first launch
+    float4 *partial;         // n_chunks * width * height partial sums (needed when n_chunks > 1)
     float4 *accum;
     uint32_t *aov_prim;  // may be null
     float *aov_t;
@@ -45,7 +52,10 @@ struct PtTraceParams {
 };
 
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).
-hipError_t pt_launch_trace(const PtTraceParams &p, uint32_t stack_depth, bool detailed_stats, hipStream_t stream);
+// order_valid: in/out, whether p.order holds an order from an earlier launch of the same image size.
+hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, bool *order_valid, hipStream_t stream);
+// Work items per tile for a launch of n_frames (1 = frames are added straight onto the running sum).
+uint32_t pt_trace_num_chunks(uint32_t n_frames, uint32_t chunk_frames, uint32_t stack_depth);
 // Bytes of global stack pt_launch_trace needs for this image/tree, 0 if the LDS stack suffices.
 size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth);
 

@@ -291,6 +291,12 @@ __device__ __forceinline__ uint32_t material_u32(float m)  // WGSL u32(f32): tru
     return (uint32_t)m;
 }
 
+#ifdef PT_DIAG
+// Diagnostic build only (make diag): per-wave start/end stamps, hardware id and loop trip count.
+#define PT_DIAG_MAX_WAVES (1u << 18)
+__device__ unsigned long long g_diag[4 * PT_DIAG_MAX_WAVES];
+#endif
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -304,29 +310,52 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
     // 16x16 pixel block tile; wave w covers the 8x8 sub-tile (w&1, w>>1); lane -> (l&7, l>>3)
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    // work item = (chunk of frames, tile); tiles are visited in P.order when given
+    // with an order (costliest tile first) all chunks of a tile are adjacent: longest job first
+    uint32_t chunk, tile;
+    if (P.order) {
+        const uint32_t t = blockIdx.x / P.launch_chunks;
+        chunk = P.chunk_base + (blockIdx.x - t * P.launch_chunks);
+        tile = P.order[t];
+    } else {
+        const uint32_t c = blockIdx.x / P.n_tiles;
+        chunk = P.chunk_base + c;
+        tile = blockIdx.x - c * P.n_tiles;
+    }
+    const unsigned long long cost_t0 = P.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+    const uint32_t x = tbx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = tby * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t frame_begin = chunk * P.chunk_frames;
+    const uint32_t frame_end = min(P.n_frames, frame_begin + P.chunk_frames);
 
     __shared__ uint32_t smem[PT_LDS_STACK * PT_BLOCK];
     Stack<OVERFLOW> stack{&smem[tid], nullptr, 0};
     if (OVERFLOW) {
-        stack.spill = P.gstack + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PT_BLOCK + tid);
-        stack.pitch = (size_t)gridDim.x * gridDim.y * PT_BLOCK;
+        stack.spill = P.gstack + ((size_t)blockIdx.x * PT_BLOCK + tid);
+        stack.pitch = (size_t)gridDim.x * PT_BLOCK;
     }
 
+#ifdef PT_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t diag_iters = 0;
+#endif
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool active = (x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0;
+    const bool in_image = (x < P.cols) && (y < P.rows) && frame_begin < frame_end && P.spp > 0;
+    bool active = in_image;
 
     const PtDeviceScene &sc = P.sc;
     const size_t pix = (size_t)y * P.width + x;
+    // a single chunk adds frame after frame onto the stored sum (same order as separate dispatches);
+    // several chunks each produce a partial sum that accumulate_kernel adds in chunk order
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) acc = P.accum[pix];
+    if (active && P.n_chunks == 1) acc = P.accum[pix];
 
     // compute.wgsl:109
     const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
     const float fspp = (float)P.spp;
 
-    uint32_t frame = 0, sample = 0;
+    uint32_t frame = frame_begin, sample = 0;
     uint32_t sx = 0, sy = 0, sz = 0, sw = 0;  // HybridTaus state
     v3 frame_sum = V3(0.0f, 0.0f, 0.0f);
     // per-path state
@@ -355,7 +384,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
                     frame_sum = V3(0.0f, 0.0f, 0.0f);
                     sample = 0;
                     frame++;
-                    if (frame == P.n_frames) { active = false; break; }
+                    if (frame == frame_end) { active = false; break; }
                 }
             }
             if (sample == 0) {
@@ -383,6 +412,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
     advance(false, V3(0.0f, 0.0f, 0.0f));
 
     while (active) {
+#ifdef PT_DIAG
+        diag_iters++;
+#endif
         cn.rays++;
         const Closest c = hit_scene<STATS>(sc, cur, stack, cn);
         const HitRecord h = make_record(sc, cur, c);
@@ -439,8 +471,30 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
         advance(path_done, result);
     }
 
-    if ((x < P.cols) && (y < P.rows) && P.n_frames > 0 && P.spp > 0) P.accum[pix] = acc;
+    if (in_image) {
+        if (P.n_chunks == 1) P.accum[pix] = acc;
+        else P.partial[(size_t)chunk * P.width * P.height + pix] = acc;
+    }
 
+    if (P.cost && lane == 0) {
+        // wall time of this wave in 10 ns ticks: next launch's tile order is built from it
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - cost_t0;
+        atomicAdd(&P.cost[tile], (uint32_t)(dt > 0xFFFFFFull ? 0xFFFFFFull : dt));
+    }
+#ifdef PT_DIAG
+    {
+        const uint32_t wid = blockIdx.x * (PT_BLOCK / 64) + wave;
+        uint32_t it = diag_iters;
+        for (int off = 32; off > 0; off >>= 1) it = max(it, (uint32_t)__shfl_xor(it, off, 64));
+        const uint32_t wrays = wave_sum(cn.rays);
+        if (lane == 0 && wid < PT_DIAG_MAX_WAVES) {
+            g_diag[4 * wid + 0] = diag_t0;
+            g_diag[4 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+            g_diag[4 * wid + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+            g_diag[4 * wid + 3] = ((unsigned long long)wrays << 32) | it;
+        }
+    }
+#endif
     // one atomic per wave and counter
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 2;
@@ -474,6 +528,53 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     if (Q.p) { Q.p[3 * i] = h.p.x; Q.p[3 * i + 1] = h.p.y; Q.p[3 * i + 2] = h.p.z; }
     if (Q.normal) { Q.normal[3 * i] = h.normal.x; Q.normal[3 * i + 1] = h.normal.y; Q.normal[3 * i + 2] = h.normal.z; }
     if (Q.front) Q.front[i] = h.front ? 1u : 0u;
+}
+
+// Builds the tile visiting order for the next launch: tiles sorted by measured cost, costliest
+// first (1024 linear buckets of the maximum; ties in arbitrary order -- the order only affects
+// scheduling, never results).  One block; clears the cost array for the next measurement.
+__global__ __launch_bounds__(1024) void order_kernel(uint32_t *cost, uint32_t *order, uint32_t n_tiles)
+{
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t maxc;
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) maxc = 1;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < n_tiles; i += 1024) m = max(m, cost[i]);
+    atomicMax(&maxc, m);
+    __syncthreads();
+    const float scale = 1023.0f / (float)maxc;
+    for (uint32_t i = tid; i < n_tiles; i += 1024) atomicAdd(&hist[1023u - min(1023u, (uint32_t)((float)cost[i] * scale))], 1u);
+    __syncthreads();
+    // exclusive scan of the histogram (bucket 0 = costliest)
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < 1024; b++) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tiles; i += 1024) {
+        const uint32_t b = 1023u - min(1023u, (uint32_t)((float)cost[i] * scale));
+        order[atomicAdd(&hist[b], 1u)] = i;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tiles; i += 1024) cost[i] = 0;
+}
+
+// Adds the per-chunk partial sums onto the running sum, in chunk order (deterministic).
+__global__ __launch_bounds__(256) void accumulate_kernel(float4 *accum, const float4 *partial, uint32_t width, uint32_t height,
+                                                         uint32_t cols, uint32_t rows, uint32_t n_chunks)
+{
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t pix = (size_t)y * width + x, npix = (size_t)width * height;
+    float4 a = accum[pix];
+    for (uint32_t k = 0; k < n_chunks; k++) {
+        const float4 p = partial[k * npix + pix];
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    accum[pix] = a;
 }
 
 // ---- accumulation read-out ----------------------------------------------------------------
@@ -534,12 +635,17 @@ size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_dep
     return bx * by * PT_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
 }
 
-hipError_t pt_launch_trace(const PtTraceParams &p, uint32_t stack_depth, bool detailed_stats, hipStream_t stream)
+uint32_t pt_trace_num_chunks(uint32_t n_frames, uint32_t chunk_frames, uint32_t stack_depth)
 {
-    const dim3 grid((p.width + 15u) / 16u, (p.height + 15u) / 16u, 1), block(PT_BLOCK, 1, 1);
-    if (grid.x == 0 || grid.y == 0) return hipSuccess;
-    const bool overflow = spill_entries(stack_depth) > 0;
-    if (overflow && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
+    // trees deeper than the LDS stack spill per launched thread: keep one chunk so the spill
+    // buffer stays width*height columns
+    if (spill_entries(stack_depth) > 0 || chunk_frames == 0 || n_frames <= chunk_frames) return 1;
+    return (n_frames + chunk_frames - 1) / chunk_frames;
+}
+
+static hipError_t launch_items(PtTraceParams p, bool overflow, bool detailed_stats, hipStream_t stream)
+{
+    const dim3 grid(p.n_tiles * p.launch_chunks, 1, 1), block(PT_BLOCK, 1, 1);
 #define PT_LAUNCH(ST, OV) hipLaunchKernelGGL((trace_kernel<ST, OV>), grid, block, 0, stream, p)
     if (overflow) {
         if (detailed_stats) PT_LAUNCH(true, true); else PT_LAUNCH(false, true);
@@ -548,6 +654,50 @@ hipError_t pt_launch_trace(const PtTraceParams &p, uint32_t stack_depth, bool de
     }
 #undef PT_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, bool *order_valid, hipStream_t stream)
+{
+    p.tiles_x = (p.width + 15u) / 16u;
+    p.tiles_y = (p.height + 15u) / 16u;
+    p.n_tiles = p.tiles_x * p.tiles_y;
+    if (p.n_tiles == 0 || p.n_frames == 0) return hipSuccess;
+    p.n_chunks = pt_trace_num_chunks(p.n_frames, p.chunk_frames, stack_depth);
+    if (p.n_chunks == 1) p.chunk_frames = p.n_frames;
+    if (p.n_chunks > 1 && !p.partial) return hipErrorInvalidValue;
+    if ((uint64_t)p.n_tiles * p.n_chunks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const bool overflow = spill_entries(stack_depth) > 0;
+    if (overflow && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
+    uint32_t *const order_buf = const_cast<uint32_t *>(p.order);
+    const bool can_order = order_buf && p.cost && order_valid;
+    hipError_t e = hipSuccess;
+    p.chunk_base = 0;
+    if (can_order && !*order_valid && p.n_chunks > 1) {
+        // no cost map yet: measure on the first chunk in natural order, then sort
+        p.order = nullptr;
+        p.launch_chunks = 1;
+        e = launch_items(p, overflow, detailed_stats, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, p.cost, order_buf, p.n_tiles);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        *order_valid = true;
+        p.chunk_base = 1;
+    }
+    p.order = (can_order && *order_valid) ? order_buf : nullptr;
+    p.launch_chunks = p.n_chunks - p.chunk_base;
+    e = launch_items(p, overflow, detailed_stats, stream);
+    if (e != hipSuccess) return e;
+    if (can_order) {
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, p.cost, order_buf, p.n_tiles);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        *order_valid = true;
+    }
+    if (p.n_chunks > 1) {
+        hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
+                           p.width, p.height, p.cols, p.rows, p.n_chunks);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth)
@@ -566,6 +716,13 @@ hipError_t pt_launch_ray_query(const PtRayQuery &q, uint32_t stack_depth, hipStr
     else hipLaunchKernelGGL((ray_query_kernel<false>), grid, block, 0, stream, q);
     return hipGetLastError();
 }
+
+#ifdef PT_DIAG
+extern "C" int pt_diag_read(void *host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 hipError_t pt_launch_resolve(const float4 *accum, uint32_t n_pixels, float4 *out_f, uint32_t *out_u8, int mode, hipStream_t stream)
 {

@@ -82,6 +82,30 @@ def test_render_frames_equals_repeated_render(pt, scenes):
     b.close()
 
 
+def test_chunked_launch_matches_sequential_within_summation_order(pt, scenes):
+    """Many frames in one call are split into work items whose partial sums are added in a fixed
+    order: same samples as separate dispatches, fp32 summation order differs (<= 1e-6 relative),
+    and the result is reproducible run to run."""
+    scene = scenes.cornell()
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(1, 5, 1e-4, 1000.0)
+    n = 70
+    rs = [pt.Renderer(scene, 96, 54, settings=st) for _ in range(3)]
+    for r in rs:
+        r.set_sky_cube(sky)
+    for f in range(n):
+        rs[0].render(100 + 2 * f)
+    rs[1].render_frames(100, 2, n)
+    rs[2].render_frames(100, 2, n)
+    a, b, c = (r.read_sum() for r in rs)
+    assert np.array_equal(b.view(np.uint32), c.view(np.uint32)), "chunked launch is not reproducible"
+    assert np.array_equal(a[..., 3], b[..., 3]) and (a[..., 3] == n).all()
+    np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-6)
+    assert rs[0].stats()["rays"] == rs[1].stats()["rays"]
+    for r in rs:
+        r.close()
+
+
 def test_reference_dispatch_leaves_bottom_rows(pt, po, scenes):
     scene = scenes.three_balls()
     st = pt.Settings(1, 4, 1e-4, 1000.0)
