@@ -311,7 +311,7 @@ static hit_t hit_scene(ctx_t *cx, ray_t ray)
     pto_node node = sc->nodes[0];
     pto_node stack[PTO_STACK_CAP];
     uint32_t sp = 0, deepest = 0;
-    float nearest = 9999.0f;
+    float nearest = 9999.0f;   /* lowered by triangle hits only: compute.wgsl:242, 288 */
     for (;;) {
         const uint32_t contents = node.left;
         if (node.count == 0) {

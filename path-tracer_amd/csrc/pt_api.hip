@@ -46,6 +46,7 @@ struct pt_ctx {
     uint2 *node_meta = nullptr;
     float4 *tri_pos = nullptr, *tri_nrm = nullptr;
     uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0;
+    float4 root_pair[4] = {};
 
     float4 *sky = nullptr;
     uint32_t sky_size = 0;
@@ -54,11 +55,13 @@ struct pt_ctx {
     size_t gstack_bytes = 0;
     uint32_t gstack_cap = 0;
 
-    float4 *partial = nullptr;  // per-chunk partial sums of multi-frame launches
-    size_t partial_bytes = 0;
-    uint32_t chunk_frames = 0;  // 0 = choose per call
-    uint32_t *tile_cost = nullptr, *tile_order = nullptr;  // load balancing: see order_kernel
-    bool order_valid = false;
+    // work-item planning (see plan_kernel)
+    uint32_t *tile_cost = nullptr, *tile_sorted = nullptr;
+    uint2 *tile_items = nullptr;
+    uint4 *items = nullptr;
+    float4 *partial = nullptr;
+    uint32_t item_cap = 0, n_tiles = 0, resident_waves = 5120;
+    bool cost_valid = false;
 
     void *scratch = nullptr;  // read-back staging for resolve
     size_t scratch_bytes = 0;
@@ -141,6 +144,7 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.node_meta = ctx->node_meta;
     sc.n_nodes = ctx->n_nodes;
     sc.root_token = ctx->root_token;
+    for (int k = 0; k < 4; k++) sc.root_pair[k] = ctx->root_pair[k];
     sc.tri_pos = ctx->tri_pos;
     sc.tri_nrm = ctx->tri_nrm;
     sc.sky = ctx->sky;
@@ -201,10 +205,17 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_NUM_COUNTERS * sizeof(unsigned long long)), "counters");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 2 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
-    const size_t n_tiles = (size_t)((width + 15u) / 16u) * ((height + 15u) / 16u);
+    const size_t n_tiles = pt_trace_num_tiles(width, height);
+    ctx->n_tiles = (uint32_t)n_tiles;
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_cost, n_tiles * sizeof(uint32_t)), "tile cost");
-    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_order, n_tiles * sizeof(uint32_t)), "tile order");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sorted, n_tiles * sizeof(uint32_t)), "tile order");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_items, n_tiles * sizeof(uint2)), "tile items");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
+    if (rc == PT_OK) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->resident_waves = (uint32_t)prop.multiProcessorCount * 20u;  // 5 waves per SIMD at the kernel's register use
+    }
     if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_t, 0, n * sizeof(float)), "clear");
@@ -233,8 +244,10 @@ void pt_destroy(pt_ctx *ctx)
     dev_free(ctx->sky);
     dev_free(ctx->gstack);
     dev_free(ctx->partial);
+    dev_free(ctx->items);
     dev_free(ctx->tile_cost);
-    dev_free(ctx->tile_order);
+    dev_free(ctx->tile_sorted);
+    dev_free(ctx->tile_items);
     dev_free(ctx->scratch);
     delete ctx;
 }
@@ -331,6 +344,8 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
     PT_HIP(ctx, hipMemcpy(ctx->tri_nrm, h_nrm.data(), h_nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
     ctx->n_nodes = n_nodes;
     ctx->root_token = token_of(0);
+    if (nodes[0].triangle_count == 0)
+        for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
     ctx->bvh_depth = max_depth;
     return PT_OK;
 }
@@ -454,44 +469,49 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     p.gstack = ctx->gstack;
     p.gstack_cap = gs ? ctx->bvh_depth : 0;
-    p.order = ctx->tile_order;
-    p.cost = ctx->tile_cost;
-    if (getenv("PTRT_NO_ORDER")) p.order = nullptr, p.cost = nullptr;  // tuning aid
+    p.refill_lanes = 48;
+    if (const char *env = getenv("PTRT_REFILL_LANES")) p.refill_lanes = (uint32_t)atoi(env);  // tuning aid
 
-    // Frames per work item: enough items per tile to balance the chip (about 8), few enough
-    // that a lane's next path can start while its neighbours finish theirs (up to 32).
-    uint32_t chunk = ctx->chunk_frames ? ctx->chunk_frames : std::min(32u, std::max(4u, (n_frames + 7u) / 8u));
-    if (const char *env = getenv("PTRT_CHUNK_FRAMES")) chunk = (uint32_t)atoi(env);  // tuning aid
-    // One launch covers at most max_chunks work items per tile so that the partial sums stay
-    // under ~4 GiB, and few enough frames that the per-lane 32-bit ray counter cannot wrap.
-    const size_t image_bytes = (size_t)ctx->width * ctx->height * sizeof(float4);
-    const uint32_t max_chunks = (uint32_t)std::max<size_t>(8, std::min<size_t>(256, ((size_t)4 << 30) / image_bytes));
+    PtSchedule sch{};
+    sch.cost = ctx->tile_cost;
+    sch.sorted = ctx->tile_sorted;
+    sch.tile_items = ctx->tile_items;
+    sch.cost_valid = &ctx->cost_valid;
+    uint32_t per_slot = 12;
+    if (const char *env = getenv("PTRT_ITEMS_PER_SLOT")) per_slot = (uint32_t)atoi(env);  // tuning aid
+    sch.wanted_items = ctx->resident_waves * per_slot;
+    sch.default_chunk = 32;
+    sch.min_planned_frames = 16;
+    sch.probe_frames = 4;
+    if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
+
+    // the per-lane ray counter is 32 bits: bound the frames of one launch
     const uint64_t per_frame = (uint64_t)ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);
     if (per_frame >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render: spp*depth too large");
-    const uint32_t max_frames = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / per_frame, 0x7FFFFFFFull);
+    const uint32_t max_frames = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / per_frame, 1u << 20);
     if (max_frames == 0) return fail(ctx, PT_ERR_LIMIT, "pt_render: spp*depth too large");
 
     uint32_t done = 0;
     while (done < n_frames) {
-        uint32_t batch = n_frames - done;
-        if (chunk && (uint64_t)chunk * max_chunks < batch) batch = chunk * max_chunks;
-        batch = std::min(batch, max_frames);
+        const uint32_t batch = std::min(n_frames - done, max_frames);
         p.time0 = time0 + done * stride;
         p.n_frames = batch;
-        p.chunk_frames = chunk;
-        const uint32_t n_chunks = pt_trace_num_chunks(batch, chunk, ctx->bvh_depth);
-        if (n_chunks > 1) {
-            const size_t need = (size_t)n_chunks * image_bytes;
-            if (need > ctx->partial_bytes) {
+        if (batch >= sch.min_planned_frames && !gs) {
+            const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, sch);
+            if (cap > ctx->item_cap) {
                 PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                dev_free(ctx->items);
                 dev_free(ctx->partial);
-                ctx->partial_bytes = 0;
-                PT_HIP(ctx, hipMalloc((void **)&ctx->partial, need));
-                ctx->partial_bytes = need;
+                ctx->item_cap = 0;
+                PT_HIP(ctx, hipMalloc((void **)&ctx->items, (size_t)cap * sizeof(uint4)));
+                PT_HIP(ctx, hipMalloc((void **)&ctx->partial, (size_t)cap * 64u * sizeof(float4)));
+                ctx->item_cap = cap;
             }
         }
-        p.partial = ctx->partial;
-        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, &ctx->order_valid, ctx->stream));
+        sch.items = ctx->items;
+        sch.partial = ctx->partial;
+        sch.item_cap = ctx->item_cap;
+        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
         done += batch;
         ctx->frames += batch;
         p.aov_prim = nullptr;  // the AOV belongs to the first frame of the call

@@ -7,8 +7,10 @@
 #include "pt_layout.h"
 #include "pt_math.h"
 
-#define PT_BLOCK 256        // 4 waves; each wave owns an 8x8 pixel tile of a 16x16 block tile
-#define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (24 KiB per block)
+#define PT_BLOCK 256        // threads per workgroup of the small kernels
+#define PT_TRACE_BLOCK 64   // megakernel: one wave per workgroup ...
+#define PT_TILE 8u          // ... which owns an 8x8 pixel tile
+#define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
@@ -20,6 +22,7 @@ struct PtDeviceScene {
     const uint2 *node_meta;  // (first, count) per node, read for big leaves only
     uint32_t n_nodes;
     uint32_t root_token;
+    float4 root_pair[4];     // the root's two children (device node format), valid if the root is interior
     // triangles in leaf order: 3 float4 each {a, original index} {b-a, 0} {c-a, 0} / {na} {nb} {nc}
     const float4 *tri_pos;
     const float4 *tri_nrm;
@@ -36,13 +39,11 @@ struct PtTraceParams {
     uint32_t cols, rows;     // pixels actually rendered (smaller under PT_FLAG_REFERENCE_DISPATCH)
     uint32_t spp, depth;
     uint32_t time0, stride, n_frames;
-    uint32_t chunk_frames;   // frames per work item; items of one tile write separate partial sums
-    uint32_t n_chunks;       // filled in by pt_launch_trace
+    uint32_t refill_lanes;   // run the shading block once this many lanes of a wave wait for it
     uint32_t tiles_x, tiles_y, n_tiles;  // filled in by pt_launch_trace
-    uint32_t chunk_base, launch_chunks;  // filled in by pt_launch_trace (chunks covered by one launch)
-    const uint32_t *order;   // optional: n_tiles entries, rewritten after each launch (costliest tile first)
-    uint32_t *cost;          // optional: n_tiles wave-time sums, zero before the first launch
-    float4 *partial;         // n_chunks * width * height partial sums (needed when n_chunks > 1)
+    const uint4 *items;      // filled in by pt_launch_trace: {tile, first frame, frame count, 0} per work item
+    float4 *partial;         // filled in by pt_launch_trace: 64 partial sums per work item
+    uint32_t *cost;          // filled in by pt_launch_trace: per-tile wave time of this launch (10 ns ticks)
     float4 *accum;
     uint32_t *aov_prim;  // may be null
     float *aov_t;
@@ -51,11 +52,26 @@ struct PtTraceParams {
     uint32_t gstack_cap;
 };
 
+// Scheduling state owned by the context; every pointer is device memory.
+struct PtSchedule {
+    uint32_t *cost;        // n_tiles, zero-initialised
+    uint32_t *sorted;      // n_tiles
+    uint2 *tile_items;     // n_tiles
+    uint4 *items;          // item_cap
+    float4 *partial;       // item_cap * 64
+    uint32_t item_cap;
+    bool *cost_valid;      // host flag: cost holds a measurement of this image
+    uint32_t wanted_items;        // work items a plan aims for (a multiple of the resident-wave capacity)
+    uint32_t default_chunk;       // frames per item when there is no measurement to plan from
+    uint32_t min_planned_frames;  // shorter launches run one item per tile (exact sequential sums)
+    uint32_t probe_frames;        // frames rendered directly to obtain the first measurement
+};
+
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).
-// order_valid: in/out, whether p.order holds an order from an earlier launch of the same image size.
-hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, bool *order_valid, hipStream_t stream);
-// Work items per tile for a launch of n_frames (1 = frames are added straight onto the running sum).
-uint32_t pt_trace_num_chunks(uint32_t n_frames, uint32_t chunk_frames, uint32_t stack_depth);
+hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, const PtSchedule &sch, hipStream_t stream);
+uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height);
+// Item-table entries a launch of n_frames can need.
+uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule &sch);
 // Bytes of global stack pt_launch_trace needs for this image/tree, 0 if the LDS stack suffices.
 size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth);
 

@@ -15,6 +15,8 @@
 // sample/frame immediately, so a wave only idles when every lane has run out of frames.
 #include "pt_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 struct Ray {
@@ -27,19 +29,19 @@ __device__ __forceinline__ v3 f4_xyz(float4 a) { return V3(a.x, a.y, a.z); }
 // Entries 0..PT_LDS_STACK-1 live in LDS at [entry][lane]; deeper entries (only trees deeper
 // than PT_LDS_STACK, and then only the rays that actually get that deep) spill to a
 // per-thread column of a global buffer.
-template <bool OVERFLOW>
+template <bool OVERFLOW, int BLOCK>
 struct Stack {
-    uint32_t *lds;     // &smem[threadIdx.x]; entry e at lds[e * PT_BLOCK]
+    uint32_t *lds;     // &smem[threadIdx.x]; entry e at lds[e * BLOCK]
     uint32_t *spill;   // &gstack[global thread]; entry e at spill[(e - PT_LDS_STACK) * pitch]
     size_t pitch;
     __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
     {
-        if (!OVERFLOW || sp < PT_LDS_STACK) lds[sp * PT_BLOCK] = v;
+        if (!OVERFLOW || sp < PT_LDS_STACK) lds[sp * BLOCK] = v;
         else spill[(size_t)(sp - PT_LDS_STACK) * pitch] = v;
     }
     __device__ __forceinline__ uint32_t pop(uint32_t sp)
     {
-        if (!OVERFLOW || sp < PT_LDS_STACK) return lds[sp * PT_BLOCK];
+        if (!OVERFLOW || sp < PT_LDS_STACK) return lds[sp * BLOCK];
         return spill[(size_t)(sp - PT_LDS_STACK) * pitch];
     }
 };
@@ -78,10 +80,21 @@ __device__ __forceinline__ float hit_aabb(v3 o, v3 inv, float4 lo, float4 hi)
     return (tmin > tmax || tmax < 0.0f) ? 99999.0f : tmin;
 }
 
-// hitScene, compute.wgsl:214-302.  Spheres in array order, then the BVH with the shader's
-// own near-first order, prune rule (nearest updated by triangle hits only) and strict '<'.
+// hitScene, compute.wgsl:214-302, split into "begin" (spheres in array order, traversal set-up)
+// and "step" (one interior-node or one leaf visit) so that a wave can interleave rays that are
+// at different points of their walk.  The walk itself is the shader's: near child first by
+// hitAabb entry distance, prune distance lowered by triangle hits only, strict '<' everywhere.
+struct Walk {
+    Closest rec;
+    v3 inv;          // 1 / direction
+    float nearest;   // prune distance (compute.wgsl:242)
+    uint32_t node;   // token of the node to visit next
+    uint32_t sp;     // stack entries in use
+};
+
+// Returns true if there is a BVH to walk (w.node/w.sp valid), false if the hit is already final.
 template <bool STATS, typename StackT>
-__device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray &ray, StackT stack, Counters &cn)
+__device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
 {
     Closest rec;
     rec.hit = false;
@@ -89,112 +102,138 @@ __device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray 
     rec.t = 0.0f;
     rec.index = 0;
     rec.u = rec.v = 0.0f;
-
     const v3 o = ray.o, d = ray.d;
     // hitSphere, compute.wgsl:304-350
-    {
-        const float a = dot3(d, d);
-        const float den = 2.0f * a;
-        const float a4 = 4.0f * a;
-        for (uint32_t i = 0; i < sc.n_spheres; i++) {
-            const float4 s0 = sc.spheres[2 * i];
-            const v3 c = f4_xyz(s0);
-            const float r = s0.w;
-            if (STATS) cn.sphere_tests++;
-            const v3 oc = o - c;
-            const float b = 2.0f * dot3(d, oc);
-            const float cc = pt_fma(-r, r, dot3(oc, oc));
-            const float disc = pt_fma(b, b, -(a4 * cc));
-            if (disc < 0.0f) continue;
-            const float sq = pt_sqrt(disc);
-            float root = (-b - sq) / den;
-            if (root <= sc.t_min || root >= sc.t_max) root = (-b + sq) / den;
-            if (root <= sc.t_min || root >= sc.t_max) continue;
-            const float mat = sc.spheres[2 * i + 1].w;
-            if (mat >= 3.0f && mat < 4.0f) {  // gizmo ring filter, compute.wgsl:342-347
-                const v3 p = v3_fma(root, d, o);
-                const v3 on = (p - c) / r;
-                const bool front = dot3(d, on) < 0.0f;
-                const v3 n = front ? on : -on;
-                const float dn = dot3(d, n);
-                if (!(dn <= 0.2f && dn >= -0.2f)) continue;
-            }
-            if (!rec.hit || root < rec.t) {
-                rec.hit = true;
-                rec.t = root;
-                rec.index = i;
-                if (STATS) cn.sphere_accept++;
-            }
+    const float a = dot3(d, d);
+    const float den = 2.0f * a;
+    const float a4 = 4.0f * a;
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        const float4 s0 = sc.spheres[2 * i];
+        const v3 c = f4_xyz(s0);
+        const float r = s0.w;
+        if (STATS) cn.sphere_tests++;
+        const v3 oc = o - c;
+        const float b = 2.0f * dot3(d, oc);
+        const float cc = pt_fma(-r, r, dot3(oc, oc));
+        const float disc = pt_fma(b, b, -(a4 * cc));
+        if (disc < 0.0f) continue;
+        const float sq = pt_sqrt(disc);
+        float root = (-b - sq) / den;
+        if (root <= sc.t_min || root >= sc.t_max) root = (-b + sq) / den;
+        if (root <= sc.t_min || root >= sc.t_max) continue;
+        const float mat = sc.spheres[2 * i + 1].w;
+        if (mat >= 3.0f && mat < 4.0f) {  // gizmo ring filter, compute.wgsl:342-347
+            const v3 p = v3_fma(root, d, o);
+            const v3 on = (p - c) / r;
+            const bool front = dot3(d, on) < 0.0f;
+            const v3 n = front ? on : -on;
+            const float dn = dot3(d, n);
+            if (!(dn <= 0.2f && dn >= -0.2f)) continue;
+        }
+        if (!rec.hit || root < rec.t) {
+            rec.hit = true;
+            rec.t = root;
+            rec.index = i;
+            if (STATS) cn.sphere_accept++;
         }
     }
+    w.rec = rec;
+    w.inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.nearest = 9999.0f;
+    w.node = sc.root_token;
+    w.sp = 0;
+    if (sc.n_nodes == 0) return false;
+    if (sc.root_token & PT_TOKEN_LEAF) return true;
+    // First visit (the root's two children) from wave-uniform registers instead of memory: most
+    // rays of an outdoor scene end their walk right here.
+    if (STATS) cn.interior++;
+    float d1 = hit_aabb(o, w.inv, sc.root_pair[0], sc.root_pair[1]);
+    float d2 = hit_aabb(o, w.inv, sc.root_pair[2], sc.root_pair[3]);
+    uint32_t k1 = __float_as_uint(sc.root_pair[0].w), k2 = __float_as_uint(sc.root_pair[2].w);
+    if (d1 > d2) {
+        const float td = d1; d1 = d2; d2 = td;
+        const uint32_t tk = k1; k1 = k2; k2 = tk;
+    }
+    if (d1 > w.nearest) return false;  // stack is empty: walk over (compute.wgsl:263-265)
+    w.node = k1;
+    if (d2 < w.nearest) stack.push(w.sp++, k2);
+    return true;
+}
 
-    if (sc.n_nodes == 0) return rec;
-
-    const v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float nearest = 9999.0f;
-    uint32_t cur = sc.root_token;
-    uint32_t sp = 0;
-    for (;;) {
-        if (!(cur & PT_TOKEN_LEAF)) {
-            if (STATS) cn.interior++;
-            const float4 *pn = sc.nodes + 2 * (size_t)cur;  // children cur, cur+1: 64 contiguous bytes
-            const float4 l0 = pn[0], l1 = pn[1], r0 = pn[2], r1 = pn[3];
-            float d1 = hit_aabb(o, inv, l0, l1);
-            float d2 = hit_aabb(o, inv, r0, r1);
-            uint32_t k1 = __float_as_uint(l0.w), k2 = __float_as_uint(r0.w);
-            if (d1 > d2) {
-                const float td = d1; d1 = d2; d2 = td;
-                const uint32_t tk = k1; k1 = k2; k2 = tk;
-            }
-            if (d1 > nearest) {
-                if (sp == 0) break;
-                cur = stack.pop(--sp);
-            } else {
-                cur = k1;
-                if (d2 < nearest) stack.push(sp++, k2);
-            }
+// One node visit.  Returns true when the walk is over (stack empty, compute.wgsl:264, 292).
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
+{
+    const v3 o = ray.o, d = ray.d;
+    const uint32_t cur = w.node;
+    if (!(cur & PT_TOKEN_LEAF)) {
+        if (STATS) cn.interior++;
+        const float4 *pn = sc.nodes + 2 * (size_t)cur;  // children cur, cur+1: 64 contiguous bytes
+        const float4 l0 = pn[0], l1 = pn[1], r0 = pn[2], r1 = pn[3];
+        float d1 = hit_aabb(o, w.inv, l0, l1);
+        float d2 = hit_aabb(o, w.inv, r0, r1);
+        uint32_t k1 = __float_as_uint(l0.w), k2 = __float_as_uint(r0.w);
+        if (d1 > d2) {
+            const float td = d1; d1 = d2; d2 = td;
+            const uint32_t tk = k1; k1 = k2; k2 = tk;
+        }
+        if (d1 > w.nearest) {
+            if (w.sp == 0) return true;
+            w.node = stack.pop(--w.sp);
         } else {
-            uint32_t count = (cur >> 28) & 7u, first = cur & PT_TOKEN_LOW;
-            if (count == 0) {
-                const uint2 m = sc.node_meta[first];
-                first = m.x;
-                count = m.y;
-            }
-            // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
-            for (uint32_t k = 0; k < count; k++) {
-                const uint32_t slot = first + k;
-                const float4 *tp = sc.tri_pos + 3 * (size_t)slot;
-                const float4 A4 = tp[0], E1 = tp[1], E2 = tp[2];
-                if (STATS) cn.tri_tests++;
-                const v3 e1 = f4_xyz(E1), e2 = f4_xyz(E2);
-                const v3 h = cross3(d, e2);
-                const float a = dot3(e1, h);
-                if (a > -0.00001f && a < 0.00001f) continue;
-                const float f = 1.0f / a;
-                const v3 s = o - f4_xyz(A4);
-                const float u = f * dot3(s, h);
-                if (u < 0.0f || u > 1.0f) continue;
-                const v3 q = cross3(s, e1);
-                const float v = f * dot3(d, q);
-                if (v < 0.0f || u + v > 1.0f) continue;
-                const float t = f * dot3(e2, q);
-                if (t <= sc.t_min || t >= sc.t_max) continue;
-                if (!rec.hit || t < rec.t) {
-                    rec.hit = true;
-                    rec.is_tri = true;
-                    rec.t = t;
-                    rec.index = slot;
-                    rec.u = u;
-                    rec.v = v;
-                    nearest = t;
-                    if (STATS) cn.tri_accept++;
-                }
-            }
-            if (sp == 0) break;
-            cur = stack.pop(--sp);
+            w.node = k1;
+            if (d2 < w.nearest) stack.push(w.sp++, k2);
+        }
+        return false;
+    }
+    uint32_t count = (cur >> 28) & 7u, first = cur & PT_TOKEN_LOW;
+    if (count == 0) {
+        const uint2 m = sc.node_meta[first];
+        first = m.x;
+        count = m.y;
+    }
+    // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t slot = first + k;
+        const float4 *tp = sc.tri_pos + 3 * (size_t)slot;
+        const float4 A4 = tp[0], E1 = tp[1], E2 = tp[2];
+        if (STATS) cn.tri_tests++;
+        const v3 e1 = f4_xyz(E1), e2 = f4_xyz(E2);
+        const v3 h = cross3(d, e2);
+        const float a = dot3(e1, h);
+        if (a > -0.00001f && a < 0.00001f) continue;
+        const float f = 1.0f / a;
+        const v3 s = o - f4_xyz(A4);
+        const float u = f * dot3(s, h);
+        if (u < 0.0f || u > 1.0f) continue;
+        const v3 q = cross3(s, e1);
+        const float v = f * dot3(d, q);
+        if (v < 0.0f || u + v > 1.0f) continue;
+        const float t = f * dot3(e2, q);
+        if (t <= sc.t_min || t >= sc.t_max) continue;
+        if (!w.rec.hit || t < w.rec.t) {
+            w.rec.hit = true;
+            w.rec.is_tri = true;
+            w.rec.t = t;
+            w.rec.index = slot;
+            w.rec.u = u;
+            w.rec.v = v;
+            w.nearest = t;
+            if (STATS) cn.tri_accept++;
         }
     }
-    return rec;
+    if (w.sp == 0) return true;
+    w.node = stack.pop(--w.sp);
+    return false;
+}
+
+template <bool STATS, typename StackT>
+__device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray &ray, StackT stack, Counters &cn)
+{
+    Walk w;
+    if (walk_begin<STATS>(sc, ray, w, stack, cn))
+        while (!walk_step<STATS>(sc, ray, w, stack, cn)) {}
+    return w.rec;
 }
 
 // Expands the closest hit into the shader's HitRecord (compute.wgsl:334-340, 394-403).
@@ -294,7 +333,8 @@ __device__ __forceinline__ uint32_t material_u32(float m)  // WGSL u32(f32): tru
 #ifdef PT_DIAG
 // Diagnostic build only (make diag): per-wave start/end stamps, hardware id and loop trip count.
 #define PT_DIAG_MAX_WAVES (1u << 18)
-__device__ unsigned long long g_diag[4 * PT_DIAG_MAX_WAVES];
+__device__ unsigned long long g_diag[8 * PT_DIAG_MAX_WAVES];
+__device__ unsigned long long g_diag_marks[8 * 64];  // first 64 work items: realtime at every 1024th loop trip
 #endif
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -305,40 +345,45 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // ---- the megakernel ---------------------------------------------------------------------
 template <bool STATS, bool OVERFLOW>
-__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
+__global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTraceParams P)
 {
-    // 16x16 pixel block tile; wave w covers the 8x8 sub-tile (w&1, w>>1); lane -> (l&7, l>>3)
+    // one wave per workgroup = one 8x8 pixel tile; lane -> (l&7, l>>3).  Single-wave groups
+    // retire independently, so a slow wave never pins the LDS and wave slots of finished ones.
     const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    // work item = (chunk of frames, tile); tiles are visited in P.order when given
-    // with an order (costliest tile first) all chunks of a tile are adjacent: longest job first
-    uint32_t chunk, tile;
-    if (P.order) {
-        const uint32_t t = blockIdx.x / P.launch_chunks;
-        chunk = P.chunk_base + (blockIdx.x - t * P.launch_chunks);
-        tile = P.order[t];
+    const uint32_t lane = tid;
+    // Work item = some consecutive frames of one tile.  Direct mode (no item table): item i is tile i
+    // with every frame of the launch, added straight onto the stored sums.  Planned mode: the
+    // table written by plan_kernel (costliest tiles first, split into more items the costlier they
+    // are); each item leaves a partial sum that accumulate_kernel adds in item order.
+    uint32_t tile, frame_begin, frame_end;
+    if (P.items) {
+        const uint4 it = P.items[blockIdx.x];
+        if (it.z == 0) return;  // unused slot of the over-sized grid
+        tile = it.x;
+        frame_begin = it.y;
+        frame_end = it.y + it.z;
     } else {
-        const uint32_t c = blockIdx.x / P.n_tiles;
-        chunk = P.chunk_base + c;
-        tile = blockIdx.x - c * P.n_tiles;
+        tile = blockIdx.x;
+        frame_begin = 0;
+        frame_end = P.n_frames;
     }
-    const unsigned long long cost_t0 = P.cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t cost_trips = 0, cost_refills = 0;  // wave-uniform work counts: the next plan's cost estimate
     const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
-    const uint32_t x = tbx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = tby * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const uint32_t frame_begin = chunk * P.chunk_frames;
-    const uint32_t frame_end = min(P.n_frames, frame_begin + P.chunk_frames);
+    const uint32_t x = tbx * PT_TILE + (lane & 7u);
+    const uint32_t y = tby * PT_TILE + (lane >> 3);
 
-    __shared__ uint32_t smem[PT_LDS_STACK * PT_BLOCK];
-    Stack<OVERFLOW> stack{&smem[tid], nullptr, 0};
+    __shared__ uint32_t smem[PT_LDS_STACK * PT_TRACE_BLOCK];
+    Stack<OVERFLOW, PT_TRACE_BLOCK> stack{&smem[tid], nullptr, 0};
     if (OVERFLOW) {
-        stack.spill = P.gstack + ((size_t)blockIdx.x * PT_BLOCK + tid);
-        stack.pitch = (size_t)gridDim.x * PT_BLOCK;
+        stack.spill = P.gstack + ((size_t)blockIdx.x * PT_TRACE_BLOCK + tid);
+        stack.pitch = (size_t)gridDim.x * PT_TRACE_BLOCK;
     }
 
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t diag_iters = 0;
+    unsigned long long diag_a = 0, diag_b = 0, diag_c = 0, diag_s = 0;
+    uint32_t diag_steps = 0;
 #endif
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool in_image = (x < P.cols) && (y < P.rows) && frame_begin < frame_end && P.spp > 0;
@@ -346,10 +391,8 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
 
     const PtDeviceScene &sc = P.sc;
     const size_t pix = (size_t)y * P.width + x;
-    // a single chunk adds frame after frame onto the stored sum (same order as separate dispatches);
-    // several chunks each produce a partial sum that accumulate_kernel adds in chunk order
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active && P.n_chunks == 1) acc = P.accum[pix];
+    if (active && !P.items) acc = P.accum[pix];
 
     // compute.wgsl:109
     const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
@@ -409,89 +452,132 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const PtTraceParams P)
         }
     };
 
-    advance(false, V3(0.0f, 0.0f, 0.0f));
+    // Lane modes.  SHADE: the lane's ray (if any) has its closest hit and waits for shading and
+    // for its next ray; WALK: mid-traversal; DONE: no frames left.  Shading and ray set-up cost
+    // an order of magnitude more instructions than one node visit, and most rays need only a
+    // couple of visits while a few need a hundred, so the wave keeps stepping the walkers and
+    // only runs the shading block once enough lanes wait for it (or nobody is walking).
+    enum : uint32_t { M_SHADE = 0, M_WALK = 1, M_DONE = 2 };
+    uint32_t mode = active ? M_SHADE : M_DONE;
+    Walk w;
+    w.rec.hit = w.rec.is_tri = false;
+    w.rec.t = w.rec.u = w.rec.v = 0.0f;
+    w.rec.index = 0;
+    w.inv = V3(0.0f, 0.0f, 0.0f);
+    w.nearest = 9999.0f;
+    w.node = 0;
+    w.sp = 0;
 
-    while (active) {
+    for (;;) {
+        const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
+        if ((waiting | walking) == 0ull) break;
+        cost_trips++;
+        if (walking == 0ull || (uint32_t)__popcll(waiting) >= P.refill_lanes) {
+            cost_refills++;
 #ifdef PT_DIAG
-        diag_iters++;
+            diag_iters++;
+            diag_s = clock64();
 #endif
-        cn.rays++;
-        const Closest c = hit_scene<STATS>(sc, cur, stack, cn);
-        const HitRecord h = make_record(sc, cur, c);
-        if (want_aov) {
-            P.aov_prim[pix] = h.prim;
-            P.aov_t[pix] = h.hit ? h.t : 0.0f;
-            want_aov = false;
-        }
-
-        bool path_done = false;
-        v3 result = V3(0.0f, 0.0f, 0.0f);
-        if (!h.hit) {
-            // compute.wgsl:140-143
-            if (STATS) cn.sky++;
-            result = color * sky_lookup(sc, cur.d);
-            path_done = true;
-        } else {
-            if (STATS) cn.bounces++;
-            const v3 dir = normalize3(cur.d);
-            v3 bdir = dir;
-            const uint32_t m = material_u32(h.material);
-            if (m == 1u) {
-                bdir = reflect_dir(dir, h.normal);
-            } else if (m == 2u) {
-                const float ri = h.front ? (1.0f / 1.5f) : 1.5f;
-                const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
-                const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
-                const bool cannot = ri * sin_t > 1.0f;
-                if (cannot || reflectance(cos_t, ri) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
-                else bdir = refract_dir(dir, h.normal, ri);
-            } else if (m == 3u) {
-                const float dn = dot3(initial_d, h.normal);
-                if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
-                    result = h.att;
-                    path_done = true;
+            if (mode == M_SHADE) {
+                bool path_done = false;
+                v3 result = V3(0.0f, 0.0f, 0.0f);
+                if (!need_new) {
+                    const HitRecord h = make_record(sc, cur, w.rec);
+                    if (want_aov) {
+                        P.aov_prim[pix] = h.prim;
+                        P.aov_t[pix] = h.hit ? h.t : 0.0f;
+                        want_aov = false;
+                    }
+                    if (!h.hit) {
+                        // compute.wgsl:140-143
+                        if (STATS) cn.sky++;
+                        result = color * sky_lookup(sc, cur.d);
+                        path_done = true;
+                    } else {
+                        if (STATS) cn.bounces++;
+                        const v3 dir = normalize3(cur.d);
+                        v3 bdir = dir;
+                        const uint32_t m = material_u32(h.material);
+                        if (m == 1u) {
+                            bdir = reflect_dir(dir, h.normal);
+                        } else if (m == 2u) {
+                            const float ri = h.front ? (1.0f / 1.5f) : 1.5f;
+                            const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
+                            const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
+                            const bool cannot = ri * sin_t > 1.0f;
+                            if (cannot || reflectance(cos_t, ri) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
+                            else bdir = refract_dir(dir, h.normal, ri);
+                        } else if (m == 3u) {
+                            const float dn = dot3(initial_d, h.normal);
+                            if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
+                                result = h.att;
+                                path_done = true;
+                            }
+                            limit++;  // correction, compute.wgsl:193
+                        } else {
+                            bdir = scatter_dir(dir, h.normal, seed);
+                        }
+                        if (m <= 1u && dot3(bdir, h.normal) <= 0.0f) {
+                            // compute.wgsl:151-153, 161-163: absorbed ray still sees the sky along the incoming ray
+                            if (STATS) cn.sky++;
+                            result = (color * h.att) * sky_lookup(sc, cur.d);
+                            path_done = true;
+                        }
+                        if (!path_done) {
+                            if (m != 3u) color = color * h.att;
+                            cur.o = h.p;
+                            cur.d = bdir;
+                            bounce++;
+                        }
+                    }
                 }
-                limit++;  // correction, compute.wgsl:193
-            } else {
-                bdir = scatter_dir(dir, h.normal, seed);
+                advance(path_done, result);
+                if (active) {
+                    cn.rays++;
+                    mode = walk_begin<STATS>(sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
+                } else {
+                    mode = M_DONE;
+                }
             }
-            if (m <= 1u && dot3(bdir, h.normal) <= 0.0f) {
-                // compute.wgsl:151-153, 161-163: absorbed ray still sees the sky along the incoming ray
-                if (STATS) cn.sky++;
-                result = (color * h.att) * sky_lookup(sc, cur.d);
-                path_done = true;
-            }
-            if (!path_done) {
-                if (m != 3u) color = color * h.att;
-                cur.o = h.p;
-                cur.d = bdir;
-                bounce++;
-            }
+#ifdef PT_DIAG
+            { const unsigned long long t = clock64(); diag_b += t - diag_s; }
+#endif
         }
-        advance(path_done, result);
+#ifdef PT_DIAG
+        diag_s = clock64();
+        diag_steps++;
+        if ((diag_steps & 1023u) == 0 && blockIdx.x < 64 && (diag_steps >> 10) <= 8 && lane == 0)
+            g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (mode == M_WALK) {
+            if (walk_step<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
+        }
+#ifdef PT_DIAG
+        { const unsigned long long t = clock64(); diag_a += t - diag_s; }
+#endif
     }
 
-    if (in_image) {
-        if (P.n_chunks == 1) P.accum[pix] = acc;
-        else P.partial[(size_t)chunk * P.width * P.height + pix] = acc;
-    }
+    if (P.items) P.partial[(size_t)blockIdx.x * 64u + lane] = acc;  // zeros for lanes outside the image
+    else if (in_image) P.accum[pix] = acc;
 
-    if (P.cost && lane == 0) {
-        // wall time of this wave in 10 ns ticks: next launch's tile order is built from it
-        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - cost_t0;
-        atomicAdd(&P.cost[tile], (uint32_t)(dt > 0xFFFFFFull ? 0xFFFFFFull : dt));
-    }
+    // Deterministic cost estimate (loop trips, a shading pass weighted like eight node visits), so
+    // that the plan -- and with it the order of the partial sums -- does not depend on timing.
+    if (P.cost && lane == 0) atomicAdd(&P.cost[tile], cost_trips + 8u * cost_refills);
 #ifdef PT_DIAG
     {
-        const uint32_t wid = blockIdx.x * (PT_BLOCK / 64) + wave;
+        const uint32_t wid = blockIdx.x;
         uint32_t it = diag_iters;
         for (int off = 32; off > 0; off >>= 1) it = max(it, (uint32_t)__shfl_xor(it, off, 64));
         const uint32_t wrays = wave_sum(cn.rays);
         if (lane == 0 && wid < PT_DIAG_MAX_WAVES) {
-            g_diag[4 * wid + 0] = diag_t0;
-            g_diag[4 * wid + 1] = __builtin_amdgcn_s_memrealtime();
-            g_diag[4 * wid + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
-            g_diag[4 * wid + 3] = ((unsigned long long)wrays << 32) | it;
+            g_diag[8 * wid + 0] = diag_t0;
+            g_diag[8 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+            g_diag[8 * wid + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+            g_diag[8 * wid + 3] = ((unsigned long long)wrays << 32) | it;
+            g_diag[8 * wid + 4] = diag_a;
+            g_diag[8 * wid + 5] = diag_b;
+            g_diag[8 * wid + 6] = diag_c;
+            g_diag[8 * wid + 7] = diag_steps;
         }
     }
 #endif
@@ -511,7 +597,7 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     const uint32_t tid = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * PT_BLOCK + tid;
     __shared__ uint32_t smem[PT_LDS_STACK * PT_BLOCK];
-    Stack<OVERFLOW> stack{&smem[tid], nullptr, 0};
+    Stack<OVERFLOW, PT_BLOCK> stack{&smem[tid], nullptr, 0};
     if (OVERFLOW) {
         stack.spill = Q.gstack + i;
         stack.pitch = (size_t)gridDim.x * PT_BLOCK;
@@ -530,25 +616,36 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     if (Q.front) Q.front[i] = h.front ? 1u : 0u;
 }
 
-// Builds the tile visiting order for the next launch: tiles sorted by measured cost, costliest
-// first (1024 linear buckets of the maximum; ties in arbitrary order -- the order only affects
-// scheduling, never results).  One block; clears the cost array for the next measurement.
-__global__ __launch_bounds__(1024) void order_kernel(uint32_t *cost, uint32_t *order, uint32_t n_tiles)
+// Plans the next launch from the wave time each tile cost in the previous one: tiles sorted
+// costliest first (1024 linear buckets; ties in arbitrary order), each split into
+// ceil(cost / target) items of consecutive frames, target = total cost / wanted item count.
+// Without cost data (first launch) every tile gets ceil(n_frames / default_chunk) items.
+// The plan only affects scheduling and the (fixed, per-plan) order of partial sums.
+// One workgroup.  tile_items[t] = (first item, item count); clears cost for the next measurement.
+__global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_tiles, uint32_t n_frames, uint32_t wanted_items,
+                                                    uint32_t default_chunk, uint4 *items, uint32_t item_cap, uint2 *tile_items,
+                                                    uint32_t *sorted)
 {
     __shared__ uint32_t hist[1024];
-    __shared__ uint32_t maxc;
+    __shared__ unsigned long long total;
+    __shared__ uint32_t maxc, running;
     const uint32_t tid = threadIdx.x;
     hist[tid] = 0;
-    if (tid == 0) maxc = 1;
+    if (tid == 0) { total = 0; maxc = 1; running = 0; }
     __syncthreads();
+    unsigned long long sum = 0;
     uint32_t m = 0;
-    for (uint32_t i = tid; i < n_tiles; i += 1024) m = max(m, cost[i]);
+    for (uint32_t i = tid; i < n_tiles; i += 1024) { const uint32_t c = cost[i]; sum += c; m = max(m, c); }
+    atomicAdd(&total, sum);
     atomicMax(&maxc, m);
     __syncthreads();
+    const bool have_cost = total > 0;
+    const float target = have_cost ? fmaxf(1.0f, (float)total / (float)max(wanted_items, 1u)) : 1.0f;
+    const uint32_t uniform_items = (n_frames + max(default_chunk, 1u) - 1u) / max(default_chunk, 1u);
     const float scale = 1023.0f / (float)maxc;
+    // bucket sort, bucket 0 = costliest
     for (uint32_t i = tid; i < n_tiles; i += 1024) atomicAdd(&hist[1023u - min(1023u, (uint32_t)((float)cost[i] * scale))], 1u);
     __syncthreads();
-    // exclusive scan of the histogram (bucket 0 = costliest)
     if (tid == 0) {
         uint32_t run = 0;
         for (uint32_t b = 0; b < 1024; b++) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
@@ -556,22 +653,59 @@ __global__ __launch_bounds__(1024) void order_kernel(uint32_t *cost, uint32_t *o
     __syncthreads();
     for (uint32_t i = tid; i < n_tiles; i += 1024) {
         const uint32_t b = 1023u - min(1023u, (uint32_t)((float)cost[i] * scale));
-        order[atomicAdd(&hist[b], 1u)] = i;
+        sorted[atomicAdd(&hist[b], 1u)] = i;
     }
     __syncthreads();
+    // items per tile, exclusive prefix sum in sorted order, item records
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t j = base + tid;
+        uint32_t t = 0, n = 0;
+        if (j < n_tiles) {
+            t = sorted[j];
+            n = have_cost ? (uint32_t)ceilf((float)cost[t] / target) : uniform_items;
+            n = min(max(n, 1u), n_frames);
+        }
+        // block-wide exclusive scan of n (reuse hist)
+        hist[tid] = n;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = tid >= off ? hist[tid - off] : 0;
+            __syncthreads();
+            hist[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t first = running + hist[tid] - n;
+        __syncthreads();
+        if (tid == 1023) running += hist[1023];
+        if (j < n_tiles) {
+            // if the table is full the tile collapses to the items that still fit (at least its
+            // frames are never dropped: the host sizes the table so that this cannot happen)
+            const uint32_t fit = first < item_cap ? min(n, item_cap - first) : 0;
+            tile_items[t] = make_uint2(first, fit);
+            for (uint32_t k = 0; k < fit; k++) {
+                const uint32_t fb = (uint32_t)(((unsigned long long)n_frames * k) / fit);
+                const uint32_t fe = (uint32_t)(((unsigned long long)n_frames * (k + 1)) / fit);
+                items[first + k] = make_uint4(t, fb, fe - fb, 0);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = running + tid; i < item_cap; i += 1024) items[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < n_tiles; i += 1024) cost[i] = 0;
 }
 
-// Adds the per-chunk partial sums onto the running sum, in chunk order (deterministic).
-__global__ __launch_bounds__(256) void accumulate_kernel(float4 *accum, const float4 *partial, uint32_t width, uint32_t height,
-                                                         uint32_t cols, uint32_t rows, uint32_t n_chunks)
+// Adds each tile's partial sums onto the running sum, in item order (deterministic for a given plan).
+__global__ __launch_bounds__(256) void accumulate_kernel(float4 *accum, const float4 *partial, const uint2 *tile_items, uint32_t width,
+                                                         uint32_t tiles_x, uint32_t cols, uint32_t rows)
 {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
-    const size_t pix = (size_t)y * width + x, npix = (size_t)width * height;
+    const uint2 ti = tile_items[(y / PT_TILE) * tiles_x + x / PT_TILE];
+    const uint32_t lane = (y % PT_TILE) * PT_TILE + x % PT_TILE;
+    const size_t pix = (size_t)y * width + x;
     float4 a = accum[pix];
-    for (uint32_t k = 0; k < n_chunks; k++) {
-        const float4 p = partial[k * npix + pix];
+    for (uint32_t k = 0; k < ti.y; k++) {
+        const float4 p = partial[(size_t)(ti.x + k) * 64u + lane];
         a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
     }
     accum[pix] = a;
@@ -631,21 +765,13 @@ static size_t spill_entries(uint32_t stack_depth) { return stack_depth > PT_LDS_
 
 size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth)
 {
-    const size_t bx = (width + 15u) / 16u, by = (height + 15u) / 16u;
-    return bx * by * PT_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
+    const size_t bx = (width + PT_TILE - 1u) / PT_TILE, by = (height + PT_TILE - 1u) / PT_TILE;
+    return bx * by * PT_TRACE_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
 }
 
-uint32_t pt_trace_num_chunks(uint32_t n_frames, uint32_t chunk_frames, uint32_t stack_depth)
+static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool overflow, bool detailed_stats, hipStream_t stream)
 {
-    // trees deeper than the LDS stack spill per launched thread: keep one chunk so the spill
-    // buffer stays width*height columns
-    if (spill_entries(stack_depth) > 0 || chunk_frames == 0 || n_frames <= chunk_frames) return 1;
-    return (n_frames + chunk_frames - 1) / chunk_frames;
-}
-
-static hipError_t launch_items(PtTraceParams p, bool overflow, bool detailed_stats, hipStream_t stream)
-{
-    const dim3 grid(p.n_tiles * p.launch_chunks, 1, 1), block(PT_BLOCK, 1, 1);
+    const dim3 grid(n_blocks, 1, 1), block(PT_TRACE_BLOCK, 1, 1);
 #define PT_LAUNCH(ST, OV) hipLaunchKernelGGL((trace_kernel<ST, OV>), grid, block, 0, stream, p)
     if (overflow) {
         if (detailed_stats) PT_LAUNCH(true, true); else PT_LAUNCH(false, true);
@@ -656,48 +782,62 @@ static hipError_t launch_items(PtTraceParams p, bool overflow, bool detailed_sta
     return hipGetLastError();
 }
 
-hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, bool *order_valid, hipStream_t stream)
+uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height)
 {
-    p.tiles_x = (p.width + 15u) / 16u;
-    p.tiles_y = (p.height + 15u) / 16u;
+    return ((width + PT_TILE - 1u) / PT_TILE) * ((height + PT_TILE - 1u) / PT_TILE);
+}
+
+uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule &sch)
+{
+    const uint64_t uniform = (uint64_t)n_tiles * ((n_frames + std::max(sch.default_chunk, 1u) - 1u) / std::max(sch.default_chunk, 1u));
+    const uint64_t planned = (uint64_t)n_tiles + sch.wanted_items + 1024u;
+    return (uint32_t)std::min<uint64_t>(std::max(uniform, planned), 0x7FFFFFFFull);
+}
+
+hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
+{
+    p.tiles_x = (p.width + PT_TILE - 1u) / PT_TILE;
+    p.tiles_y = (p.height + PT_TILE - 1u) / PT_TILE;
     p.n_tiles = p.tiles_x * p.tiles_y;
     if (p.n_tiles == 0 || p.n_frames == 0) return hipSuccess;
-    p.n_chunks = pt_trace_num_chunks(p.n_frames, p.chunk_frames, stack_depth);
-    if (p.n_chunks == 1) p.chunk_frames = p.n_frames;
-    if (p.n_chunks > 1 && !p.partial) return hipErrorInvalidValue;
-    if ((uint64_t)p.n_tiles * p.n_chunks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const bool overflow = spill_entries(stack_depth) > 0;
     if (overflow && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
-    uint32_t *const order_buf = const_cast<uint32_t *>(p.order);
-    const bool can_order = order_buf && p.cost && order_valid;
-    hipError_t e = hipSuccess;
-    p.chunk_base = 0;
-    if (can_order && !*order_valid && p.n_chunks > 1) {
-        // no cost map yet: measure on the first chunk in natural order, then sort
-        p.order = nullptr;
-        p.launch_chunks = 1;
-        e = launch_items(p, overflow, detailed_stats, stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, p.cost, order_buf, p.n_tiles);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        *order_valid = true;
-        p.chunk_base = 1;
+    p.cost = nullptr;
+    // Few frames, no scheduling buffers, or a spilling stack (whose buffer has one column per tile
+    // lane): one item per tile, frames added in order onto the stored sums.
+    const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost || overflow;
+    if (direct) {
+        p.items = nullptr;
+        p.partial = nullptr;
+        return launch_items(p, p.n_tiles, overflow, detailed_stats, stream);
     }
-    p.order = (can_order && *order_valid) ? order_buf : nullptr;
-    p.launch_chunks = p.n_chunks - p.chunk_base;
-    e = launch_items(p, overflow, detailed_stats, stream);
-    if (e != hipSuccess) return e;
-    if (can_order) {
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, p.cost, order_buf, p.n_tiles);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        *order_valid = true;
+    hipError_t e;
+    if (!*sch.cost_valid) {
+        // No measurement yet: render the first frames directly to get one, then plan the rest.
+        PtTraceParams first = p;
+        first.items = nullptr;
+        first.partial = nullptr;
+        first.n_frames = std::min(p.n_frames, sch.probe_frames);
+        first.cost = sch.cost;
+        if ((e = launch_items(first, p.n_tiles, overflow, detailed_stats, stream)) != hipSuccess) return e;
+        *sch.cost_valid = true;
+        p.time0 += first.n_frames * p.stride;
+        p.n_frames -= first.n_frames;
+        p.aov_prim = nullptr;
+        if (p.n_frames == 0) return hipSuccess;
     }
-    if (p.n_chunks > 1) {
-        hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
-                           p.width, p.height, p.cols, p.rows, p.n_chunks);
-        e = hipGetLastError();
-    }
-    return e;
+    const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
+    if (cap > sch.item_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk,
+                       sch.items, cap, sch.tile_items, sch.sorted);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    p.items = sch.items;
+    p.partial = sch.partial;
+    p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
+    if ((e = launch_items(p, cap, overflow, detailed_stats, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
+                       sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
+    return hipGetLastError();
 }
 
 size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth)
@@ -721,6 +861,16 @@ hipError_t pt_launch_ray_query(const PtRayQuery &q, uint32_t stack_depth, hipStr
 extern "C" int pt_diag_read(void *host, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag), bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int pt_diag_clear(void)
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_diag)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 8 * PT_DIAG_MAX_WAVES);
+}
+extern "C" int pt_diag_read_marks(void *host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag_marks), bytes, 0, hipMemcpyDeviceToHost);
 }
 #endif
 

@@ -84,7 +84,7 @@ def test_render_frames_equals_repeated_render(pt, scenes):
 
 def test_chunked_launch_matches_sequential_within_summation_order(pt, scenes):
     """Many frames in one call are split into work items whose partial sums are added in a fixed
-    order: same samples as separate dispatches, fp32 summation order differs (<= 1e-6 relative),
+    order: same samples as separate dispatches, fp32 summation order differs (<= n ulp),
     and the result is reproducible run to run."""
     scene = scenes.cornell()
     sky = scenes.sky_cube_direct(16)
@@ -100,7 +100,7 @@ def test_chunked_launch_matches_sequential_within_summation_order(pt, scenes):
     a, b, c = (r.read_sum() for r in rs)
     assert np.array_equal(b.view(np.uint32), c.view(np.uint32)), "chunked launch is not reproducible"
     assert np.array_equal(a[..., 3], b[..., 3]) and (a[..., 3] == n).all()
-    np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(b, a, rtol=n * 2.0 ** -23, atol=1e-6)  # fp32 re-association bound
     assert rs[0].stats()["rays"] == rs[1].stats()["rays"]
     for r in rs:
         r.close()

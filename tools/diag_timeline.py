@@ -18,14 +18,22 @@ scene, w, h, st, _ = scenes.CONFIGS["bunny_1080p_d8_spp256"][0](), 1920, 1080, p
 r = pt.Renderer(scene, w, h, settings=st)
 pw = min(4096, sky)
 r.set_sky_equirect(scenes.sky_equirect(pw, pw // 2), sky)
+L = pt.lib()
+L.pt_diag_clear.argtypes = []
 r.render_frames(1, 1, frames); r.sync()
 r.reset_ready_samples()
 r.render_frames(1, 1, frames); r.sync()
-nw = ((w + 15) // 16) * ((h + 15) // 16) * 4
-buf = np.zeros((nw, 4), np.uint64)
-L = pt.lib()
+L.pt_diag_clear()
+r.reset_ready_samples()
+r.render_frames(1, 1, frames); r.sync()
+import math
+chunk = int(os.environ.get("PTRT_CHUNK_FRAMES", "0")) or (frames if frames < 16 else min(32, max(4, (frames + 7) // 8)))
+nw = 1 << 18
+buf = np.zeros((nw, 8), np.uint64)
 L.pt_diag_read.argtypes = [C.c_void_p, C.c_size_t]
 assert L.pt_diag_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+buf = buf[buf[:, 1] > 0]
+nw = len(buf)
 t0, t1, hw, misc = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64), buf[:, 2], buf[:, 3]
 iters, rays = (misc & 0xFFFFFFFF).astype(np.int64), (misc >> 32).astype(np.int64)
 base = t0.min()
@@ -43,11 +51,31 @@ ts = (ev[:, 0] - base) / 100.0
 for frac in (0.05, 0.25, 0.5, 0.75, 0.9, 0.95, 0.99):
     i = np.searchsorted(ts, frac * total)
     print(f"  t={frac*total:9.1f} us ({int(frac*100):2d}%): resident waves {int(conc[min(i, len(conc)-1)])}")
+top = np.argsort(-dur)[:12]
+print("longest waves: " + ", ".join(f"[wid {int(i)} start {(t0[i]-base)/100:.0f}us dur {dur[i]:.0f}us refills {int(iters[i])} steps {int(buf[i,7])} walk_cyc {int(buf[i,4])} refill_cyc {int(buf[i,5])} rays {int(rays[i])}]" for i in top[:6]))
+late = np.argsort(-(t1 - base))[:6]
+print("last to finish: " + ", ".join(f"[wid {int(i)} start {(t0[i]-base)/100:.0f}us dur {dur[i]:.0f}us]" for i in late))
+marks = np.zeros((64, 8), np.uint64)
+L.pt_diag_read_marks.argtypes = [C.c_void_p, C.c_size_t]
+L.pt_diag_read_marks(marks.ctypes.data_as(C.c_void_p), marks.nbytes)
+for wi in (0, 2, 8):
+    ms = [(int(m) - int(base)) / 100.0 for m in marks[wi] if m]
+    print(f"wave {wi}: time (us) at every 1024th loop trip: " + " ".join(f"{m:.0f}" for m in ms))
 avg_conc = dur.sum() / total
 print(f"average resident waves {avg_conc:.0f} = {avg_conc/256:.1f} per CU")
+ta, tb, tc = buf[:, 4].astype(np.float64), buf[:, 5].astype(np.float64), buf[:, 6].astype(np.float64)
+tot = ta.sum() + tb.sum() + tc.sum()
+steps = buf[:, 7].astype(np.float64)
+print("shares of in-loop wave time: walk steps %.1f%%  shade+new ray %.1f%%" % (100 * ta.sum() / tot, 100 * tb.sum() / tot))
+print("per wave: refills %.1f, walk iterations %.1f; cycles per walk iteration %.0f, per refill %.0f; rays per refill %.1f" % (
+    iters.mean(), steps.mean(), ta.sum() / max(steps.sum(), 1), tb.sum() / max(iters.sum(), 1), rays.sum() / max(iters.sum(), 1)))
+pi = ta / np.maximum(iters, 1)
+print("hit_scene cycles per wave-iteration: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(pi[iters > 0], [10, 50, 90, 99, 100])))
+if not os.environ.get("PTRT_NO_ORDER"):
+    sys.exit(0)
 # rows of tiles: time by tile row
 bx = (w + 15) // 16
 row = (np.arange(nw) // 4) // bx
-for rr in range(0, (h + 15) // 16, 6):
+for rr in range(0, (h + 15) // 16, 3):
     m = row == rr
-    print(f"  tile row {rr:2d}: mean wave us {dur[m].mean():8.1f} iters {iters[m].mean():7.1f} rays/iter {rays[m].sum()/max(iters[m].sum(),1):5.1f} start {((t0[m].min()-base)/100):8.1f}")
+    print(f"  tile row {rr:2d}: mean wave us {dur[m].mean():8.1f} iters {iters[m].mean():7.1f} rays/iter {rays[m].sum()/max(iters[m].sum(),1):5.1f} hit_scene cyc/iter {ta[m].sum()/max(iters[m].sum(),1):8.0f} shade {tb[m].sum()/max(iters[m].sum(),1):6.0f} adv {tc[m].sum()/max(iters[m].sum(),1):6.0f}")
