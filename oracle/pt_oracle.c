@@ -35,7 +35,11 @@
  *     (fmaf) exactly where this file writes fmaf, and nowhere else (build with
  *     -ffp-contract=off);  dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x));
  *     cross(a,b).x = fma(a.y,b.z, -(a.z*b.y)) (cyclic);
- *   - '/' and sqrt are correctly rounded; normalize(v) = v * (1/sqrt(dot(v,v)));
+ *   - '/' and sqrt are correctly rounded; at four places where the shader divides several
+ *     values by one denominator (sphere normal / radius, the two sphere roots / 2a, the two
+ *     cube-face coordinates / major axis, colour / spp) the quotient is value * (1/denominator),
+ *     as WGSL's division accuracy allows;
+ *     normalize(v) = v * (1/sqrt(dot(v,v)));
  *   - min/max are IEEE minNum/maxNum (fminf/fmaxf);
  *   - sin/cos: 3-term fused Cody-Waite reduction by pi/2 + degree-7/8 minimax
  *     polynomials (pto_sincosf below); tan = sin/cos; pow(x,5) = ((x*x)*(x*x))*x;
@@ -231,13 +235,13 @@ static hit_t hit_sphere(ctx_t *cx, ray_t ray, const pto_sphere *sp, uint32_t ind
     hit_t h; memset(&h, 0, sizeof h);
     h.att = ld3(sp->albedo); h.material = sp->material; h.prim = 0x80000000u | index;
     if (disc < 0.0f) return h;
-    const float sq = sqrtf(disc), den = 2.0f * a;
-    float root = (-b - sq) / den;
-    if (root <= cx->t_min || root >= cx->t_max) root = (-b + sq) / den;
+    const float sq = sqrtf(disc), inv_den = 1.0f / (2.0f * a);
+    float root = (-b - sq) * inv_den;
+    if (root <= cx->t_min || root >= cx->t_max) root = (-b + sq) * inv_den;
     if (root <= cx->t_min || root >= cx->t_max) return h;
     h.hit = 1; h.t = root; h.p = vfma(root, ray.d, ray.o);
     const v3 pc = vsub(h.p, center);
-    const v3 on = V(pc.x / sp->radius, pc.y / sp->radius, pc.z / sp->radius);
+    const v3 on = vscale(pc, 1.0f / sp->radius);
     h.front = dot3(ray.d, on) < 0.0f;
     h.normal = h.front ? on : vneg(on);
     /* u32(material): saturating, NaN -> 0 */
@@ -358,8 +362,9 @@ static v3 sky_lookup(ctx_t *cx, v3 d)
     else if (ay >= ax)        { face = d.y < 0.0f ? 3u : 2u; scoord = d.x; tcoord = d.y < 0.0f ? -d.z : d.z; ma = ay; }
     else                      { face = d.x < 0.0f ? 1u : 0u; scoord = d.x < 0.0f ? d.z : -d.z; tcoord = -d.y; ma = ax; }
     const float size = (float)sc->sky_size;
-    const float fs = fmaf(0.5f, scoord / ma, 0.5f) * size;
-    const float ft = fmaf(0.5f, tcoord / ma, 0.5f) * size;
+    const float inv_ma = 1.0f / ma;
+    const float fs = fmaf(0.5f, scoord * inv_ma, 0.5f) * size;
+    const float ft = fmaf(0.5f, tcoord * inv_ma, 0.5f) * size;
     const uint32_t hi = sc->sky_size - 1u;
     const uint32_t i = (fs >= 0.0f) ? (fs < size ? (uint32_t)fs : hi) : 0u;   /* NaN -> 0 */
     const uint32_t j = (ft >= 0.0f) ? (ft < size ? (uint32_t)ft : hi) : 0u;
@@ -495,8 +500,7 @@ static void render_pixel(ctx_t *cx, const frame_t *fr, uint32_t x, uint32_t y, u
         float ft_dummy; float *ft = (i == 0 && aov_t) ? &aov_t[pix] : &ft_dummy;
         color = vadd(color, ray_color(cx, ray, st, sc->settings->depth, fp, ft));
     }
-    const float n = (float)spp;
-    color = V(color.x / n, color.y / n, color.z / n);
+    color = vscale(color, 1.0f / (float)spp);
     float *a = accum + pix * 4u;
     a[0] += color.x; a[1] += color.y; a[2] += color.z; a[3] += 1.0f;
 }

@@ -2,7 +2,7 @@
 //
 // Device data layout (all hipMalloc, lives for the context):
 //   accum     width*height float4   running RGB sums, .w = frame count
-//   spheres   2 float4 per sphere   {center, radius} {albedo, material}
+//   spheres   3 float4 per sphere   {center, radius} {albedo, material} {1/radius, 0, 0, 0}
 //   nodes     2 float4 per node     {min, token} {max, count}; the array is stored one node
 //                                   late so that every sibling pair (odd, even index) is one
 //                                   64-byte aligned block
@@ -41,6 +41,8 @@ struct pt_ctx {
 
     float4 *spheres = nullptr;
     uint32_t n_spheres = 0;
+    bool has_gizmo = false;
+    uint64_t paths = 0;  // rayColor calls since the last reset (every pixel runs every sample)
 
     float4 *nodes_alloc = nullptr;
     uint2 *node_meta = nullptr;
@@ -204,7 +206,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_prim, n * sizeof(uint32_t)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_NUM_COUNTERS * sizeof(unsigned long long)), "counters");
-    if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 2 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 3 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
     const size_t n_tiles = pt_trace_num_tiles(width, height);
     ctx->n_tiles = (uint32_t)n_tiles;
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_cost, n_tiles * sizeof(uint32_t)), "tile cost");
@@ -214,7 +216,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            ctx->resident_waves = (uint32_t)prop.multiProcessorCount * 20u;  // 5 waves per SIMD at the kernel's register use
+            ctx->resident_waves = (uint32_t)prop.multiProcessorCount * 4u * PT_TRACE_WAVES_PER_EU;
     }
     if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
@@ -423,8 +425,17 @@ int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
     const PtSphereData *sd = static_cast<const PtSphereData *>(sphere_data8208);
     // the storage buffer holds 256 spheres; a larger count would read past it
     const uint32_t n = sd->sphere_count > PT_MAX_SPHERES ? PT_MAX_SPHERES : sd->sphere_count;
+    std::vector<float4> packed(3 * (size_t)n);
+    ctx->has_gizmo = false;
+    for (uint32_t i = 0; i < n; i++) {
+        const PtSphere &sp = sd->spheres[i];
+        if (sp.material >= 3.0f && sp.material < 4.0f) ctx->has_gizmo = true;
+        packed[3 * i] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
+        packed[3 * i + 1] = make_float4(sp.albedo[0], sp.albedo[1], sp.albedo[2], sp.material);
+        packed[3 * i + 2] = make_float4(1.0f / sp.radius, 0.0f, 0.0f, 0.0f);
+    }
     // stream-ordered copy from pageable memory: the runtime stages the bytes before returning
-    if (n) PT_HIP(ctx, hipMemcpyAsync(ctx->spheres, sd->spheres, (size_t)n * sizeof(PtSphere), hipMemcpyHostToDevice, ctx->stream));
+    if (n) PT_HIP(ctx, hipMemcpyAsync(ctx->spheres, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     ctx->n_spheres = n;
     return PT_OK;
 }
@@ -457,6 +468,8 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     p.spp = ctx->settings.samples_per_pixel;
     p.depth = ctx->settings.depth;
+    p.inv_spp = 1.0f / (float)ctx->settings.samples_per_pixel;
+    p.has_gizmo = ctx->has_gizmo;
     p.stride = stride;
     p.accum = ctx->accum;
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
@@ -514,6 +527,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
         done += batch;
         ctx->frames += batch;
+        ctx->paths += (uint64_t)p.cols * p.rows * batch * ctx->settings.samples_per_pixel;
         p.aov_prim = nullptr;  // the AOV belongs to the first frame of the call
     }
     return PT_OK;
@@ -528,6 +542,7 @@ int pt_reset(pt_ctx *ctx)
     PT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, n * sizeof(float4), ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
     ctx->frames = 0;
+    ctx->paths = 0;
     return PT_OK;
 }
 
@@ -591,7 +606,7 @@ int pt_stats(pt_ctx *ctx, pt_stats_t *out)
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c[0];
-    out->paths = c[1];
+    out->paths = ctx->paths;
     out->interior = c[2];
     out->tri_tests = c[3];
     out->tri_accept = c[4];

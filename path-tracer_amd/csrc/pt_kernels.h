@@ -10,11 +10,14 @@
 #define PT_BLOCK 256        // threads per workgroup of the small kernels
 #define PT_TRACE_BLOCK 64   // megakernel: one wave per workgroup ...
 #define PT_TILE 8u          // ... which owns an 8x8 pixel tile
+#ifndef PT_TRACE_WAVES_PER_EU
+#define PT_TRACE_WAVES_PER_EU 5   // register budget of the megakernel: 512 / 5 -> at most 96 VGPRs
+#endif
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
-    // spheres: 2 float4 each {center, radius} {albedo, material}
+    // spheres: 3 float4 each {center, radius} {albedo, material} {1/radius, 0, 0, 0}
     const float4 *spheres;
     uint32_t n_spheres;
     // BVH: 2 float4 per node {min, token} {max, count}, indexed by the reference's node index
@@ -38,6 +41,8 @@ struct PtTraceParams {
     uint32_t width, height;  // image size (accumulation buffer pitch = width)
     uint32_t cols, rows;     // pixels actually rendered (smaller under PT_FLAG_REFERENCE_DISPATCH)
     uint32_t spp, depth;
+    bool has_gizmo;          // a sphere with material 3 exists (selects the kernel variant)
+    float inv_spp;           // 1 / spp, rounded once on the host
     uint32_t time0, stride, n_frames;
     uint32_t refill_lanes;   // run the shading block once this many lanes of a wave wait for it
     uint32_t tiles_x, tiles_y, n_tiles;  // filled in by pt_launch_trace

@@ -16,6 +16,7 @@
 #include "pt_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -105,10 +106,10 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     const v3 o = ray.o, d = ray.d;
     // hitSphere, compute.wgsl:304-350
     const float a = dot3(d, d);
-    const float den = 2.0f * a;
+    const float inv_den = 1.0f / (2.0f * a);
     const float a4 = 4.0f * a;
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
-        const float4 s0 = sc.spheres[2 * i];
+        const float4 s0 = sc.spheres[3 * i];
         const v3 c = f4_xyz(s0);
         const float r = s0.w;
         if (STATS) cn.sphere_tests++;
@@ -118,13 +119,13 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
         const float disc = pt_fma(b, b, -(a4 * cc));
         if (disc < 0.0f) continue;
         const float sq = pt_sqrt(disc);
-        float root = (-b - sq) / den;
-        if (root <= sc.t_min || root >= sc.t_max) root = (-b + sq) / den;
+        float root = (-b - sq) * inv_den;
+        if (root <= sc.t_min || root >= sc.t_max) root = (-b + sq) * inv_den;
         if (root <= sc.t_min || root >= sc.t_max) continue;
-        const float mat = sc.spheres[2 * i + 1].w;
+        const float mat = sc.spheres[3 * i + 1].w;
         if (mat >= 3.0f && mat < 4.0f) {  // gizmo ring filter, compute.wgsl:342-347
             const v3 p = v3_fma(root, d, o);
-            const v3 on = (p - c) / r;
+            const v3 on = (p - c) * sc.spheres[3 * i + 2].x;
             const bool front = dot3(d, on) < 0.0f;
             const v3 n = front ? on : -on;
             const float dn = dot3(d, n);
@@ -260,8 +261,8 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
         h.material = 0.0f;
         h.prim = __float_as_uint(sc.tri_pos[3 * (size_t)c.index].w);
     } else {
-        const float4 s0 = sc.spheres[2 * c.index], s1 = sc.spheres[2 * c.index + 1];
-        on = (h.p - f4_xyz(s0)) / s0.w;
+        const float4 s0 = sc.spheres[3 * c.index], s1 = sc.spheres[3 * c.index + 1];
+        on = (h.p - f4_xyz(s0)) * sc.spheres[3 * c.index + 2].x;
         h.att = f4_xyz(s1);
         h.material = s1.w;
         h.prim = 0x80000000u | c.index;
@@ -287,8 +288,9 @@ __device__ __forceinline__ v3 sky_lookup(const PtDeviceScene &sc, v3 d)
         face = d.x < 0.0f ? 1u : 0u; scoord = d.x < 0.0f ? d.z : -d.z; tcoord = -d.y; ma = ax;
     }
     const float size = (float)sc.sky_size;
-    const float fs = pt_fma(0.5f, scoord / ma, 0.5f) * size;
-    const float ft = pt_fma(0.5f, tcoord / ma, 0.5f) * size;
+    const float inv_ma = 1.0f / ma;
+    const float fs = pt_fma(0.5f, scoord * inv_ma, 0.5f) * size;
+    const float ft = pt_fma(0.5f, tcoord * inv_ma, 0.5f) * size;
     const uint32_t hi = sc.sky_size - 1u;
     const uint32_t i = (fs >= 0.0f) ? (fs < size ? (uint32_t)fs : hi) : 0u;
     const uint32_t j = (ft >= 0.0f) ? (ft < size ? (uint32_t)ft : hi) : 0u;
@@ -308,10 +310,14 @@ __device__ __forceinline__ v3 reflect_dir(v3 dir, v3 normal)
     const float k = 2.0f * dot3(dir, normal);
     return normalize3(v3_fma(-k, normal, dir));  // the fuzz term has weight 0 and is dropped
 }
-__device__ __forceinline__ float reflectance(float cosine, float ref_idx)
+constexpr float kRefrFront = 1.0f / 1.5f, kRefrBack = 1.5f;
+constexpr float r0_squared(float ref_idx)  // folded by the compiler with the same IEEE rounding
 {
-    const float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-    const float r0s = r0 * r0;
+    return ((1.0f - ref_idx) / (1.0f + ref_idx)) * ((1.0f - ref_idx) / (1.0f + ref_idx));
+}
+__device__ __forceinline__ float reflectance(float cosine, bool front)
+{
+    const float r0s = front ? r0_squared(kRefrFront) : r0_squared(kRefrBack);
     const float x = 1.0f - cosine, x2 = x * x;
     const float p5 = (x2 * x2) * x;
     return pt_fma(1.0f - r0s, p5, r0s);
@@ -344,8 +350,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // ---- the megakernel ---------------------------------------------------------------------
-template <bool STATS, bool OVERFLOW>
-__global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTraceParams P)
+// GIZMO: some sphere has material 3 (only then is the path's first direction kept);
+// SPP1: one sample per pixel and dispatch (the per-frame sample sum is the sample itself).
+template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1>
+__global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_kernel(const PtTraceParams P)
 {
     // one wave per workgroup = one 8x8 pixel tile; lane -> (l&7, l>>3).  Single-wave groups
     // retire independently, so a slow wave never pins the LDS and wave slots of finished ones.
@@ -372,6 +380,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
     const uint32_t x = tbx * PT_TILE + (lane & 7u);
     const uint32_t y = tby * PT_TILE + (lane >> 3);
 
+    // running sums of this item: touched once per frame, so they live in LDS, not in registers
+    __shared__ float4 lds_acc[PT_TRACE_BLOCK];
     __shared__ uint32_t smem[PT_LDS_STACK * PT_TRACE_BLOCK];
     Stack<OVERFLOW, PT_TRACE_BLOCK> stack{&smem[tid], nullptr, 0};
     if (OVERFLOW) {
@@ -391,12 +401,11 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
 
     const PtDeviceScene &sc = P.sc;
     const size_t pix = (size_t)y * P.width + x;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active && !P.items) acc = P.accum[pix];
-
-    // compute.wgsl:109
-    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
-    const float fspp = (float)P.spp;
+    {
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (active && !P.items) acc = P.accum[pix];
+        lds_acc[lane] = acc;
+    }
 
     uint32_t frame = frame_begin, sample = 0;
     uint32_t sx = 0, sy = 0, sz = 0, sw = 0;  // HybridTaus state
@@ -417,13 +426,18 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
         while (active && (need_new || path_done || bounce >= limit)) {
             if (!need_new) {
                 // rayColor returned: compute.wgsl:121
-                frame_sum = frame_sum + (path_done ? result : color);
+                const v3 path_color = path_done ? result : color;
                 path_done = false;
-                sample++;
-                if (sample == P.spp) {
+                if (!SPP1) {
+                    frame_sum = frame_sum + path_color;
+                    sample++;
+                }
+                if (SPP1 || sample == P.spp) {
                     // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
-                    const v3 mean = frame_sum / fspp;
+                    const v3 mean = (SPP1 ? path_color : frame_sum) * P.inv_spp;
+                    float4 acc = lds_acc[lane];
                     acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                    lds_acc[lane] = acc;
                     frame_sum = V3(0.0f, 0.0f, 0.0f);
                     sample = 0;
                     frame++;
@@ -439,16 +453,16 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
             const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
             const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
             const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
+            const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));  // compute.wgsl:109
             cur.o = P.fr.origin;
             cur.d = (ploc + smp) - P.fr.origin;
-            initial_d = cur.d;
+            if (GIZMO) initial_d = cur.d;
             color = V3(1.0f, 1.0f, 1.0f);
             seed = pt_hybrid_taus(sx, sy, sz, sw);
             bounce = 0;
             limit = P.depth;
             need_new = false;
             want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
-            cn.paths++;
         }
     };
 
@@ -501,13 +515,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
                         if (m == 1u) {
                             bdir = reflect_dir(dir, h.normal);
                         } else if (m == 2u) {
-                            const float ri = h.front ? (1.0f / 1.5f) : 1.5f;
+                            const float ri = h.front ? kRefrFront : kRefrBack;
                             const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
                             const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
                             const bool cannot = ri * sin_t > 1.0f;
-                            if (cannot || reflectance(cos_t, ri) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
+                            if (cannot || reflectance(cos_t, h.front) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
                             else bdir = refract_dir(dir, h.normal, ri);
-                        } else if (m == 3u) {
+                        } else if (GIZMO && m == 3u) {
                             const float dn = dot3(initial_d, h.normal);
                             if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
                                 result = h.att;
@@ -557,8 +571,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
 #endif
     }
 
-    if (P.items) P.partial[(size_t)blockIdx.x * 64u + lane] = acc;  // zeros for lanes outside the image
-    else if (in_image) P.accum[pix] = acc;
+    if (P.items) P.partial[(size_t)blockIdx.x * 64u + lane] = lds_acc[lane];  // zeros for lanes outside the image
+    else if (in_image) P.accum[pix] = lds_acc[lane];
 
     // Deterministic cost estimate (loop trips, a shading pass weighted like eight node visits), so
     // that the plan -- and with it the order of the partial sums -- does not depend on timing.
@@ -583,8 +597,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void trace_kernel(const PtTracePara
 #endif
     // one atomic per wave and counter
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
-    const int ncount = STATS ? PT_NUM_COUNTERS : 2;
+    const int ncount = STATS ? PT_NUM_COUNTERS : 1;  // paths are counted on the host
     for (int k = 0; k < ncount; k++) {
+        if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
         if (lane == 0 && s) atomicAdd(&P.counters[k], (unsigned long long)s);
     }
@@ -772,12 +787,17 @@ size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_dep
 static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool overflow, bool detailed_stats, hipStream_t stream)
 {
     const dim3 grid(n_blocks, 1, 1), block(PT_TRACE_BLOCK, 1, 1);
-#define PT_LAUNCH(ST, OV) hipLaunchKernelGGL((trace_kernel<ST, OV>), grid, block, 0, stream, p)
-    if (overflow) {
-        if (detailed_stats) PT_LAUNCH(true, true); else PT_LAUNCH(false, true);
-    } else {
-        if (detailed_stats) PT_LAUNCH(true, false); else PT_LAUNCH(false, false);
-    }
+    static const size_t lds_pad = getenv("PTRT_LDS_PAD") ? (size_t)atoi(getenv("PTRT_LDS_PAD")) : 0;  // tuning aid: lowers occupancy
+#define PT_LAUNCH(ST, OV, GZ, S1) hipLaunchKernelGGL((trace_kernel<ST, OV, GZ, S1>), grid, block, lds_pad, stream, p)
+#define PT_LAUNCH_OV(OV)                                                      \
+    do {                                                                      \
+        if (detailed_stats) PT_LAUNCH(true, OV, true, false);                 \
+        else if (p.has_gizmo) { if (p.spp == 1) PT_LAUNCH(false, OV, true, true); else PT_LAUNCH(false, OV, true, false); } \
+        else { if (p.spp == 1) PT_LAUNCH(false, OV, false, true); else PT_LAUNCH(false, OV, false, false); } \
+    } while (0)
+    if (overflow) PT_LAUNCH_OV(true);
+    else PT_LAUNCH_OV(false);
+#undef PT_LAUNCH_OV
 #undef PT_LAUNCH
     return hipGetLastError();
 }

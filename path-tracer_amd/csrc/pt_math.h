@@ -7,7 +7,8 @@
 //   * IEEE-754 binary32, round-to-nearest-even, subnormals kept, no fast-math;
 //   * a fused multiply-add exactly where pt_fma is written and nowhere else (the translation
 //     units are built with -ffp-contract=off);
-//   * correctly rounded '/' and sqrt; min/max = minNum/maxNum;
+//   * correctly rounded '/' and sqrt; sphere normal / radius, sphere roots / 2a, cube-face
+//     coordinates / major axis and colour / spp are value * (1/denominator); min/max = minNum/maxNum;
 //   * sin/cos by a 3-step fused Cody-Waite reduction and fixed minimax polynomials.
 // Host code (camera frame, scene set-up) and gfx950 kernels compile this same text.
 #pragma once
@@ -50,33 +51,59 @@ PT_HD v3 normalize3(v3 a)
 }
 
 // sin(x) and cos(x).  k = nearest integer to x*2/pi; r = x - k*pi/2 in three fused steps
-// (pi/2 split hi/mid/lo); polynomials on [-pi/4, pi/4]; quadrant from k mod 4.
-PT_HD void pt_sincos(float x, float &s_out, float &c_out)
+// (pi/2 split hi/mid/lo); on [-pi/4, pi/4]
+//   sin r = fma(s*r, fma(s, fma(s, S3, S2), S1), r)             s = r*r
+//   cos r = fma(s*s, fma(s, fma(s, C3, C2), C1), fma(-0.5, s, 1))
+// and the quadrant (k mod 4) picks the polynomial and the sign.  Both have the same Horner
+// shape, so one evaluation with per-lane coefficients serves either.
+struct pt_reduced {
+    float r, s;
+    int q;
+};
+PT_HD pt_reduced pt_reduce_pio2(float x)
 {
     const float k = pt_rint(x * 0.63661977236758134f);
     float r = pt_fma(-k, 1.57079637050628662f, x);
     r = pt_fma(-k, -4.37113882867379e-08f, r);
     r = pt_fma(-k, -1.71512451000588e-15f, r);
-    const float s = r * r;
-    float ps = pt_fma(s, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = pt_fma(s, ps, -1.6666654611e-1f);
-    ps = pt_fma(s * r, ps, r);
-    float pc = pt_fma(s, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = pt_fma(s, pc, 4.166664568298827e-2f);
-    pc = pt_fma(s * s, pc, pt_fma(-0.5f, s, 1.0f));
-    const int q = (k >= -2147483648.0f && k < 2147483648.0f) ? (int)k : 0;
-    float sv = (q & 1) ? pc : ps;
-    float cv = (q & 1) ? ps : pc;
-    if (q & 2) sv = -sv;
-    if ((q + 1) & 2) cv = -cv;
-    s_out = sv;
-    c_out = cv;
+    pt_reduced o;
+    o.r = r;
+    o.s = r * r;
+    o.q = (k >= -2147483648.0f && k < 2147483648.0f) ? (int)k : 0;
+    return o;
+}
+// use_cos selects the cosine polynomial; the caller applies the sign
+PT_HD float pt_sincos_poly(const pt_reduced &a, bool use_cos)
+{
+    const float c3 = use_cos ? 2.443315711809948e-5f : -1.9515295891e-4f;
+    const float c2 = use_cos ? -1.388731625493765e-3f : 8.3321608736e-3f;
+    const float c1 = use_cos ? 4.166664568298827e-2f : -1.6666654611e-1f;
+    float p = pt_fma(a.s, c3, c2);
+    p = pt_fma(a.s, p, c1);
+    const float m = a.s * (use_cos ? a.s : a.r);
+    const float base = use_cos ? pt_fma(-0.5f, a.s, 1.0f) : a.r;
+    return pt_fma(m, p, base);
 }
 PT_HD float pt_sin(float x)
 {
-    float s, c;
-    pt_sincos(x, s, c);
-    return s;
+    const pt_reduced a = pt_reduce_pio2(x);
+    const float v = pt_sincos_poly(a, (a.q & 1) != 0);
+    return (a.q & 2) ? -v : v;
+}
+PT_HD float pt_cos(float x)
+{
+    const pt_reduced a = pt_reduce_pio2(x);
+    const float v = pt_sincos_poly(a, (a.q & 1) == 0);
+    return ((a.q + 1) & 2) ? -v : v;
+}
+PT_HD void pt_sincos(float x, float &s_out, float &c_out)
+{
+    const pt_reduced a = pt_reduce_pio2(x);
+    const float ps = pt_sincos_poly(a, false), pc = pt_sincos_poly(a, true);
+    const float sv = (a.q & 1) ? pc : ps;
+    const float cv = (a.q & 1) ? ps : pc;
+    s_out = (a.q & 2) ? -sv : sv;
+    c_out = ((a.q + 1) & 2) ? -cv : cv;
 }
 PT_HD float pt_tan(float x)
 {
