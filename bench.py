@@ -99,6 +99,7 @@ def main():
 
     pt = _pkgload.load()
     scenes = importlib.import_module("path_tracer_amd.scenes")
+    multi = importlib.import_module("path_tracer_amd.multi")
     scene, w, h, settings, frames = build_workload(pt, scenes, args.workload)
     if args.frames:
         frames = args.frames
@@ -114,9 +115,9 @@ def main():
 
     def step(i: int):
         accum.zero_()
-        r.render_frames(1 + rank + i * frames * world, world, frames)
+        r.render_frames(*multi.frames_for_rank(rank, world, 1 + i * frames * world, frames * world))
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            multi.reduce_sum_to_root(accum, 0)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -134,10 +135,10 @@ def main():
     for i in range(args.steps):
         accum.zero_()
         ev[i][0].record(stream)
-        r.render_frames(1 + rank + i * frames * world, world, frames)
+        r.render_frames(*multi.frames_for_rank(rank, world, 1 + i * frames * world, frames * world))
         ev[i][1].record(stream)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            multi.reduce_sum_to_root(accum, 0)
     fence()
     elapsed = time.perf_counter() - t0
     rays = r.stats()["rays"] - rays_before
@@ -156,7 +157,7 @@ def main():
         # same frames (untimed), priced with the work model above
         r.set_flags(pt.PT_FLAG_DETAILED_STATS)
         r.reset_ready_samples()
-        r.render_frames(1 + rank, world, frames)
+        r.render_frames(*multi.frames_for_rank(rank, world, 1, frames * world))
         st = r.stats()
         r.set_flags(0)
         flops, abytes = algorithmic_flops(st), algorithmic_bytes(st, w * h * frames)

@@ -612,8 +612,10 @@ static void update_bounds(bvh_t *b, uint32_t ni)   /* bvh.rs:68-89 */
         const float *vs[3] = { t->a, t->b, t->c };
         for (int k = 0; k < 3; k++)
             for (int ax = 0; ax < 3; ax++) {
-                n->mn[ax] = fminf(n->mn[ax], vs[k][ax]);
-                n->mx[ax] = fmaxf(n->mx[ax], vs[k][ax]);
+                /* f32::min/max: a NaN vertex is ignored; on +0/-0 ties the earlier value stays
+                 * (which zero Rust's minnum lowering returns is not specified) */
+                if (vs[k][ax] < n->mn[ax]) n->mn[ax] = vs[k][ax];
+                if (vs[k][ax] > n->mx[ax]) n->mx[ax] = vs[k][ax];
             }
     }
 }

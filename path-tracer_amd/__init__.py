@@ -101,6 +101,12 @@ def lib() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PtError(-4, f"{LIB_PATH} not built; run `make -C path-tracer_amd/csrc` (there is no CPU fallback)")
+        try:
+            # torch bundles its own HIP runtime under the same soname; whichever copy is loaded
+            # first serves the whole process, and torch only works with its own.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, res, args in ABI:
             fn = getattr(handle, name)

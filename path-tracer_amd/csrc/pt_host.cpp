@@ -32,7 +32,8 @@ struct BvhBuilder {
     const PtTriangle *tris;
     uint32_t used;
 
-    // Bvh::update_bounds, src/scene/bvh.rs:68-89 (f32::min/max ignore a NaN operand, as fminf/fmaxf do)
+    // Bvh::update_bounds, src/scene/bvh.rs:68-89.  f32::min/max ignore a NaN operand; which of +0/-0
+    // they return on a tie is not specified, here the earlier value stays.
     void update_bounds(uint32_t ni)
     {
         PtNode &n = nodes[ni];
@@ -41,8 +42,8 @@ struct BvhBuilder {
             const float *verts[3] = {t.a, t.b, t.c};
             for (const float *v : verts)
                 for (int ax = 0; ax < 3; ax++) {
-                    n.min_corner[ax] = std::fmin(n.min_corner[ax], v[ax]);
-                    n.max_corner[ax] = std::fmax(n.max_corner[ax], v[ax]);
+                    if (v[ax] < n.min_corner[ax]) n.min_corner[ax] = v[ax];
+                    if (v[ax] > n.max_corner[ax]) n.max_corner[ax] = v[ax];
                 }
         }
     }

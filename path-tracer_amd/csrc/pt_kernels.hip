@@ -560,6 +560,11 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #ifdef PT_DIAG
         diag_s = clock64();
         diag_steps++;
+        {
+            const unsigned long long wk = __ballot(mode == M_WALK);
+            const unsigned long long lf = __ballot(mode == M_WALK && (w.node & PT_TOKEN_LEAF));
+            diag_c += ((unsigned long long)__popcll(wk) << 40) | ((unsigned long long)__popcll(lf) << 20) | (lf ? 1ull : 0ull);
+        }
         if ((diag_steps & 1023u) == 0 && blockIdx.x < 64 && (diag_steps >> 10) <= 8 && lane == 0)
             g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
 #endif

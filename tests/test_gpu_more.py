@@ -1,0 +1,215 @@
+"""More HIP-vs-oracle parity through the C ABI: explicit ray queries, every material, deep trees
+whose stack spills past LDS, the equirect->cube kernel, read-outs and input validation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+        f"{what}: {int((a.view(np.uint32) != b.view(np.uint32)).sum())} of {a.size} values differ"
+
+
+def _pair(pt, po, scene, w, h, st, sky, flags=0):
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV | flags)
+    if sky is not None:
+        r.set_sky_cube(sky)
+    return r, po.from_scene(scene, w, h, st, sky)
+
+
+def test_trace_rays_matches_oracle(pt, po, scenes):
+    scene = scenes.bunny(n=12)
+    scene.spheres.append(pt.Sphere((0.5, 0.3, 0.5), 0.3, (1, 1, 1), pt.Material.Dielectric))
+    st = pt.Settings(1, 4, 1e-4, 1000.0)
+    r, osc = _pair(pt, po, scene, 16, 16, st, None)
+    rng = np.random.RandomState(5)
+    n = 3000
+    o = rng.uniform(-2, 2, (n, 3)).astype(np.float32) + np.array([0, 1.5, 2], np.float32)
+    d = (np.array([0, 0.5, -1], np.float32) - o + rng.normal(0, 0.6, (n, 3))).astype(np.float32)
+    d[::7] *= 0.01          # un-normalised directions scale t
+    d[5::11, 0] = 0.0       # axis-parallel components -> infinite inverse direction
+    gp, gt, gpos, gn, gf = r.trace_rays(o, d)
+    op, ot, opos, on, of = osc.trace_rays(o, d)
+    assert np.array_equal(gp, op), f"{int((gp != op).sum())} primitive ids differ"
+    hit = op != 0xFFFFFFFF
+    assert hit.sum() > 200 and (op[hit] < 0x80000000).sum() > 50
+    _exact(gt[hit], ot[hit], "t")
+    _exact(gpos[hit], opos[hit], "hit point")
+    _exact(gn[hit], on[hit], "normal")
+    assert np.array_equal(gf[hit], of[hit])
+    r.close()
+
+
+def test_all_materials_and_spp_gt_1(pt, po, scenes):
+    """Metal, dielectric, gizmo and an out-of-range material id, several samples per dispatch."""
+    S, M = pt.Sphere, pt.Material
+    spheres = [S((0, 0, -1), 0.5, (0.8, 0.3, 0.3), M.Diffuse), S((1, 0, -1), 0.5, (1, 1, 1), M.Dielectric),
+               S((-1, 0, -1), 0.5, (0.8, 0.6, 0.2), M.Metal), S((0, 1.0, -1), 0.4, (0.2, 0.9, 0.2), M.Gizmo),
+               S((0, -100.5, -1), 100.0, (0.8, 0.8, 0.0), M.Diffuse), S((2.2, 0.2, -1.5), 0.7, (0.3, 0.3, 0.9), M.Diffuse)]
+    cam = pt.Camera.from_yaw_pitch((0.0, 0.6, 1.8), -90.0, -8.0)
+    scene = pt.Scene(spheres, scenes.cornell().triangles, cam)
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(3, 12, 1e-4, 1000.0)
+    r, osc = _pair(pt, po, scene, 128, 72, st, sky)
+    # material id 7 takes the shader's default branch (compute.wgsl:196-200)
+    buf = pt.pack_spheres(spheres)
+    buf["spheres"][0][5]["material"] = 7.0
+    r._ck(r._l.pt_set_spheres(r._ctx, buf.ctypes.data))
+    osc.spheres[:] = buf.view(np.uint8).reshape(-1)
+    acc = np.zeros((72, 128, 4), np.float32)
+    rays = 0
+    for t in (11, 12):
+        r.render(t)
+        acc, prim, tt, s = osc.render(t, acc, want_aov=True)
+        rays += s["rays"]
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim)
+    assert {0x80000001, 0x80000002, 0x80000003, 0x80000005} <= set(np.unique(prim).tolist())
+    _exact(gt, tt, "primary t")
+    _exact(r.read_sum(), acc, "radiance")
+    assert r.stats()["rays"] == rays
+    r.close()
+
+
+def test_deep_tree_spills_past_lds_stack(pt, po, scenes):
+    """Sheets stacked ever closer to z = 0 give the midpoint builder a chain (each split peels off
+    the farthest sheet); a ray towards them enters the near child and pushes the far one at every
+    level, so the stack grows to the depth of the tree -- far past its LDS part."""
+    n = 60
+    tris = np.zeros(n, pt.TRIANGLE_DTYPE)
+    z = -8.0 * 2.0 ** -np.arange(n, dtype=np.float64)
+    tris["a"] = np.stack([-1 * np.ones(n), -1 * np.ones(n), z], 1)
+    tris["b"] = np.stack([3 * np.ones(n), -1 * np.ones(n), z], 1)
+    tris["c"] = np.stack([-1 * np.ones(n), 3 * np.ones(n), z], 1)
+    tris["na"] = tris["nb"] = tris["nc"] = (0, 0, 1)
+    tris["albedo"] = 1.0
+    scene = pt.Scene([pt.Sphere((0.5, 0.5, 1.0), 0.2, (0.8, 0.8, 0.0))], tris,
+                     pt.Camera(origin=(0.5, 0.5, 2.0), vfov=50.0))
+    st = pt.Settings(1, 6, 1e-4, 1000.0)
+    r, osc = _pair(pt, po, scene, 96, 64, st, scenes.sky_cube_direct(8))
+    assert r.stats()["bvh_depth"] > 40
+    acc = np.zeros((64, 96, 4), np.float32)
+    for t in (1, 2, 3):
+        r.render(t)
+        acc, prim, tt, s = osc.render(t, acc, want_aov=True)
+    assert s["max_stack"] > 24, "scene does not exercise the spill path"
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim) and (prim < 0x80000000).sum() > 20
+    _exact(r.read_sum(), acc, "radiance")
+    # many frames in one call also stay on the one-item-per-tile path for spilling trees
+    r.reset_ready_samples()
+    r.render_frames(1, 1, 20)
+    acc = np.zeros((64, 96, 4), np.float32)
+    for t in range(1, 21):
+        osc.render(t, acc)
+    _exact(r.read_sum(), acc, "radiance, 20 frames in one call")
+    r.close()
+
+
+def test_sphere_only_and_empty_scenes(pt, po, scenes):
+    sky = scenes.sky_cube_direct(8)
+    st = pt.Settings(2, 5, 1e-4, 1000.0)
+    for spheres in ([], scenes.three_balls().spheres):
+        scene = pt.Scene(list(spheres), np.zeros(0, pt.TRIANGLE_DTYPE), scenes.three_balls().camera)
+        r, osc = _pair(pt, po, scene, 64, 40, st, sky)
+        r.render(9)
+        acc, prim, tt, s = osc.render(9, want_aov=True)
+        gprim, _ = r.read_aov()
+        assert np.array_equal(gprim, prim)
+        _exact(r.read_sum(), acc, "radiance")
+        r.close()
+
+
+def test_depth_zero_and_no_sky(pt, po, scenes):
+    scene = scenes.cornell()
+    for depth in (0, 1):
+        st = pt.Settings(2, depth, 1e-4, 1000.0)
+        r, osc = _pair(pt, po, scene, 32, 20, st, None)
+        r.render(4)
+        acc, *_ = osc.render(4)
+        _exact(r.read_sum(), acc, f"depth {depth}")
+        r.close()
+
+
+def test_equirect_to_cube_matches_oracle(pt, po, scenes):
+    pano = scenes.sky_equirect(256, 128)
+    pano[..., 0] += np.arange(256, dtype=np.float32)[None, :] / 256.0      # make columns distinguishable
+    scene = scenes.three_balls()
+    r = pt.Renderer(scene, 32, 20, settings=pt.Settings(1, 4, 1e-4, 1000.0))
+    r.set_sky_equirect(pano, 64)
+    got = r.read_sky_cube(64)
+    want = po.equirect_to_cube(pano, 64)
+    _exact(got, want, "cube texels")
+    # and the renderer uses it
+    r.render(2)
+    acc, *_ = po.from_scene(scene, 32, 20, pt.Settings(1, 4, 1e-4, 1000.0), want).render(2)
+    _exact(r.read_sum(), acc, "radiance with generated cube")
+    r.close()
+
+
+def test_readouts(pt, scenes):
+    scene = scenes.three_balls()
+    r = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0))
+    r.set_sky_cube(scenes.sky_cube_direct(8))
+    for t in range(4):
+        r.render(t)
+    s, m, q = r.read_sum(), r.read_mean(), r.read_rgba8()
+    assert (s[..., 3] == 4).all() and (m[..., 3] == 1).all()
+    np.testing.assert_array_equal(m[..., :3], s[..., :3] / np.float32(4.0))
+    want = np.rint(np.clip(m, 0, 1) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(q, want)
+    r.reset_ready_samples()
+    assert not r.read_sum().any() and r.stats()["frames"] == 0 and r.stats()["rays"] == 0
+    assert not r.read_mean().any()
+    r.close()
+
+
+def test_bind_accum_to_torch_tensor(pt, scenes):
+    import torch
+    scene = scenes.three_balls()
+    a = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0))
+    b = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0), stream=torch.cuda.current_stream().cuda_stream)
+    tens = torch.zeros((36, 64, 4), dtype=torch.float32, device="cuda")
+    b.bind_accum(tens.data_ptr())
+    assert b.accum_device_ptr() == tens.data_ptr()
+    for r in (a, b):
+        r.set_sky_cube(scenes.sky_cube_direct(8))
+        r.render(1)
+        r.render(2)
+        r.sync()
+    assert np.array_equal(a.read_sum(), tens.cpu().numpy())
+    a.close()
+    b.close()
+
+
+def test_malformed_bvh_is_rejected(pt, scenes):
+    scene = scenes.cornell()
+    r = pt.Renderer(scene, 16, 16)
+    nodes = scene.nodes.copy()
+    bad = nodes.copy()
+    bad["left"][0] = 0                      # child index not after its parent: would loop forever
+    with pytest.raises(pt.PtError):
+        r.set_mesh(scene.triangles, bad, scene.triangle_indices)
+    bad = nodes.copy()
+    bad["left"][0] = len(nodes)             # children out of range
+    with pytest.raises(pt.PtError):
+        r.set_mesh(scene.triangles, bad, scene.triangle_indices)
+    leaf = int(np.nonzero(nodes["count"])[0][0])
+    bad = nodes.copy()
+    bad["count"][leaf] = 1000               # leaf range past the index array
+    with pytest.raises(pt.PtError):
+        r.set_mesh(scene.triangles, bad, scene.triangle_indices)
+    idx = scene.triangle_indices.copy()
+    idx[0] = 99                             # triangle index out of range
+    with pytest.raises(pt.PtError):
+        r.set_mesh(scene.triangles, nodes, idx)
+    r.set_mesh(scene.triangles, nodes, scene.triangle_indices)      # still usable afterwards
+    r.render(1)
+    assert r.read_sum()[..., 3].min() == 1
+    st = pt.Settings(0, 4, 1e-4, 1000.0)
+    r.set_settings(st)
+    with pytest.raises(pt.PtError):
+        r.render(1)
+    r.close()

@@ -1,0 +1,119 @@
+"""CPU tests of the product's host side (no GPU): C-ABI surface, BVH builder, plane/sphere packing,
+.obj ingestion -- each checked against the oracle's independent restatement or a hand-made case."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pt):
+    header = open(os.path.join(ROOT, "include", "ptrt.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pt_status"}
+    lib = pt.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"libptrt.so lacks {missing}"
+    assert declared == {n for n, _, _ in pt.ABI}, "python binding and header disagree"
+
+
+def test_create_without_gpu_fails_cleanly(pt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    rc = pt.lib().pt_create(0, 64, 64, C.byref(ctx))
+    assert rc < 0 and not ctx.value
+    assert b"HIP" in pt.lib().pt_last_error(None) or b"device" in pt.lib().pt_last_error(None)
+    with pytest.raises(pt.PtError):
+        pt.Renderer(pt.Scene([], np.zeros(0, pt.TRIANGLE_DTYPE), pt.Camera()), 8, 8)
+
+
+def test_create_rejects_bad_arguments(pt):
+    lib = pt.lib()
+    assert lib.pt_create(0, 64, 64, None) == -1
+    ctx = C.c_void_p()
+    assert lib.pt_create(0, 0, 64, C.byref(ctx)) == -1
+    assert lib.pt_render(None, 0) == -1 and lib.pt_reset(None) == -1
+    lib.pt_destroy(None)
+
+
+@pytest.mark.parametrize("maker", ["cornell", "blob8", "blob24", "random", "clustered"])
+def test_bvh_builder_matches_oracle(pt, po, scenes, maker):
+    if maker == "cornell":
+        tris = scenes.cornell().triangles
+    elif maker.startswith("blob"):
+        tris = scenes.blob_mesh(int(maker[4:]))
+    else:
+        rng = np.random.RandomState(3)
+        n = 500
+        tris = np.zeros(n, pt.TRIANGLE_DTYPE)
+        base = rng.uniform(-5, 5, (n, 3)) if maker == "random" else np.round(rng.uniform(-1, 1, (n, 3)), 1)
+        tris["a"] = base
+        tris["b"] = base + rng.uniform(-0.3, 0.3, (n, 3))
+        tris["c"] = base + rng.uniform(-0.3, 0.3, (n, 3))
+    nodes, idx = pt.bvh_build(tris)
+    onodes, oidx = po.bvh_build(tris)
+    assert np.array_equal(idx, oidx)
+    assert nodes.tobytes() == onodes.tobytes()
+
+
+def test_bvh_empty_and_bad_arguments(pt):
+    nodes, idx = pt.bvh_build(np.zeros(0, pt.TRIANGLE_DTYPE))
+    assert len(nodes) == 0 and len(idx) == 0
+    assert pt.lib().pt_bvh_build(None, 3, None, None) == -1
+    assert b"null" in pt.lib().pt_host_error()
+
+
+def test_plane_triangles_match_oracle(pt, po):
+    for q, u, v in [((0, 0, -1), (2, 0, 0), (0, 0, 2)), ((1, 2, 3), (0.3, 0.1, -0.7), (0.2, 0.9, 0.4))]:
+        got = pt.Plane(q, u, v, (0.2, 0.4, 0.6), pt.Material.Metal).triangles()
+        want = po.plane_triangles(q, u, v, (0.2, 0.4, 0.6), 1)
+        assert got.tobytes() == want.tobytes()
+        assert np.allclose(np.linalg.norm(got["na"], axis=1), 1.0, atol=1e-6)
+        assert got["material"].tolist() == [1, 1]
+        # plane.rs:18-38: (q, q+u, q+v) and (q+u+v, q+u, q+v)
+        assert np.allclose(got[1]["a"], np.add(np.add(q, u), v), atol=1e-6)
+
+
+def test_pack_spheres(pt, po):
+    sph = [pt.Sphere((i, 2 * i, -i), 0.5 + i, (0.1, 0.2, 0.3), pt.Material(i % 4)) for i in range(5)]
+    buf = pt.pack_spheres(sph)
+    assert buf.tobytes() == po.pack_spheres(sph).tobytes()
+    assert buf["count"][0] == 5 and buf["spheres"][0][4]["material"] == 0.0 and buf["spheres"][0][3]["material"] == 3.0
+    many = [pt.Sphere((0, 0, 0), 1.0, (1, 1, 1))] * 300
+    assert pt.pack_spheres(many)["count"][0] == 256      # clamped like sphere.rs:116-125
+
+
+def test_obj_loader(pt, tmp_path):
+    p = tmp_path / "quad.obj"
+    p.write_text("# comment\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\n"
+                 "f 1//1 2//1 3//1 4//1\nf -4/9/1 -3/9/1 -2/9/1\n")
+    tris = pt.load_obj(str(p))
+    assert len(tris) == 3                                   # quad fan-triangulated + one triangle
+    assert tris[0]["a"].tolist() == [0, 0, 0] and tris[0]["c"].tolist() == [1, 1, 0]
+    assert tris[1]["b"].tolist() == [1, 1, 0] and tris[1]["c"].tolist() == [0, 1, 0]
+    assert tris[2]["a"].tolist() == [0, 0, 0] and tris[2]["c"].tolist() == [1, 1, 0]   # negative indices
+    assert (tris["na"] == [0, 0, 1]).all() and (tris["albedo"] == 1).all() and (tris["material"] == 0).all()
+    # no vn: smooth normals from the faces (the reference would panic)
+    q = tmp_path / "nonormals.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    t = pt.load_obj(str(q))
+    assert len(t) == 1 and np.allclose(t[0]["na"], [0, 0, 1])
+    with pytest.raises(pt.PtError):
+        pt.load_obj(str(tmp_path / "missing.obj"))
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(pt.PtError):
+        pt.load_obj(str(bad))
+
+
+def test_default_camera_basis(pt, scenes):
+    cam = scenes.default_camera()
+    # yaw -90, pitch 0 (camera.rs:127-128, 214-226): forward ~ -z with the f32 cos(-90 deg) residue
+    assert abs(cam.forward[2] + 1) < 1e-6 and abs(cam.forward[0]) < 1e-6 and cam.forward[0] != 0
+    assert np.allclose(cam.right, [1, 0, 0], atol=1e-6) and np.allclose(cam.up, [0, 1, 0], atol=1e-6)
+    assert cam.buffer().tobytes()[12:16] == np.float32(1.0).tobytes()      # focal length at offset 12

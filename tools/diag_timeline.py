@@ -69,6 +69,12 @@ steps = buf[:, 7].astype(np.float64)
 print("shares of in-loop wave time: walk steps %.1f%%  shade+new ray %.1f%%" % (100 * ta.sum() / tot, 100 * tb.sum() / tot))
 print("per wave: refills %.1f, walk iterations %.1f; cycles per walk iteration %.0f, per refill %.0f; rays per refill %.1f" % (
     iters.mean(), steps.mean(), ta.sum() / max(steps.sum(), 1), tb.sum() / max(iters.sum(), 1), rays.sum() / max(iters.sum(), 1)))
+dc = buf[:, 6]
+walkers, leaf_lanes, leaf_trips = (dc >> np.uint64(40)).astype(np.float64), ((dc >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(np.float64), (dc & np.uint64(0xFFFFF)).astype(np.float64)
+print("walk trips: %.3g total, mean active walkers %.1f, trips with a leaf lane %.1f%%, mean leaf lanes in those %.1f" % (
+    steps.sum(), walkers.sum() / steps.sum(), 100 * leaf_trips.sum() / steps.sum(), leaf_lanes.sum() / max(leaf_trips.sum(), 1)))
+heavy = steps > np.percentile(steps, 90)
+print("top-10%% waves by trips hold %.1f%% of trips; their mean active walkers %.1f" % (100 * steps[heavy].sum() / steps.sum(), walkers[heavy].sum() / steps[heavy].sum()))
 pi = ta / np.maximum(iters, 1)
 print("hit_scene cycles per wave-iteration: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(pi[iters > 0], [10, 50, 90, 99, 100])))
 if not os.environ.get("PTRT_NO_ORDER"):
