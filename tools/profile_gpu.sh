@@ -16,5 +16,5 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
   name=$(echo $pass | tr ' ' '+' | cut -c1-40)
   timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -- python3 $B $ARGS > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass failed: $pass"; tail -3 $OUT/pmc_$name.log; }
 done
-python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT $ARGS > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

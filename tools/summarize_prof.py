@@ -27,3 +27,24 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection
         n[row["Counter_Name"]] += 1
     for k in acc:
         print("  %-32s %.6g  (n=%d)" % (k, acc[k] / n[k], n[k]))
+
+# HBM traffic of the planned megakernel launches (the largest dispatches), corrected as measured by
+# tools/ubench/fetch_calib: FETCH_SIZE tallies every TCC->fabric read request as 64 B although a
+# coalesced stream moves 128 B per request (factor 2); WRITE_SIZE is exact.
+import json
+vals = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    xs = []
+    for f in glob.glob(os.path.join(root, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
+        xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "trace_kernel<false" in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
+    big = [x for x in xs if x > 0.5 * max(xs)] if xs else []
+    vals[name] = sum(big) / len(big) if big else None
+if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
+    args = sys.argv[2:]
+    frames = int(args[args.index("--frames") + 1]) if "--frames" in args else 256
+    workload = args[args.index("--workload") + 1] if "--workload" in args else "bunny_1080p_d8_spp256"
+    rec = {"workload": workload, "frames": frames, "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+           "hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0,
+           "correction": "2 x FETCH_SIZE (128-B read requests tallied at 64 B on gfx950) + WRITE_SIZE"}
+    json.dump(rec, open(os.path.join(root, "pmc_traffic.json"), "w"))
+    print("== traffic:", rec)
