@@ -336,6 +336,59 @@ __device__ __forceinline__ uint32_t material_u32(float m)  // WGSL u32(f32): tru
     return (uint32_t)m;
 }
 
+// One iteration of rayColor's loop body after hitScene (compute.wgsl:140-203): either the path ends
+// (returns true, `result` = its colour) or `cur` becomes the bounce ray and `color` the new throughput.
+template <bool STATS, bool GIZMO>
+__device__ __forceinline__ bool shade_ray(const PtDeviceScene &sc, Ray &cur, const Closest &c, v3 &color, float seed, uint32_t &bounce,
+                                          uint32_t &limit, v3 initial_d, v3 &result, uint32_t &prim, Counters &cn)
+{
+    const HitRecord h = make_record(sc, cur, c);
+    prim = h.prim;
+    if (!h.hit) {
+        // compute.wgsl:140-143
+        if (STATS) cn.sky++;
+        result = color * sky_lookup(sc, cur.d);
+        return true;
+    }
+    if (STATS) cn.bounces++;
+    bool path_done = false;
+    const v3 dir = normalize3(cur.d);
+    v3 bdir = dir;
+    const uint32_t m = material_u32(h.material);
+    if (m == 1u) {
+        bdir = reflect_dir(dir, h.normal);
+    } else if (m == 2u) {
+        const float ri = h.front ? kRefrFront : kRefrBack;
+        const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
+        const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
+        const bool cannot = ri * sin_t > 1.0f;
+        if (cannot || reflectance(cos_t, h.front) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
+        else bdir = refract_dir(dir, h.normal, ri);
+    } else if (GIZMO && m == 3u) {
+        const float dn = dot3(initial_d, h.normal);
+        if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
+            result = h.att;
+            path_done = true;
+        }
+        limit++;  // correction, compute.wgsl:193
+    } else {
+        bdir = scatter_dir(dir, h.normal, seed);
+    }
+    if (m <= 1u && dot3(bdir, h.normal) <= 0.0f) {
+        // compute.wgsl:151-153, 161-163: absorbed ray still sees the sky along the incoming ray
+        if (STATS) cn.sky++;
+        result = (color * h.att) * sky_lookup(sc, cur.d);
+        path_done = true;
+    }
+    if (!path_done) {
+        if (m != 3u) color = color * h.att;
+        cur.o = h.p;
+        cur.d = bdir;
+        bounce++;
+    }
+    return path_done;
+}
+
 #ifdef PT_DIAG
 // Diagnostic build only (make diag): per-wave start/end stamps, hardware id and loop trip count.
 #define PT_DIAG_MAX_WAVES (1u << 18)
@@ -351,8 +404,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // ---- the megakernel ---------------------------------------------------------------------
 // GIZMO: some sphere has material 3 (only then is the path's first direction kept);
-// SPP1: one sample per pixel and dispatch (the per-frame sample sum is the sample itself).
-template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1>
+// SPP1: one sample per pixel and dispatch (the per-frame sample sum is the sample itself);
+// DIRECT: no item table -- work item i is tile i with every frame, added straight onto the sums.
+template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_kernel(const PtTraceParams P)
 {
     // one wave per workgroup = one 8x8 pixel tile; lane -> (l&7, l>>3).  Single-wave groups
@@ -364,7 +418,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     // table written by plan_kernel (costliest tiles first, split into more items the costlier they
     // are); each item leaves a partial sum that accumulate_kernel adds in item order.
     uint32_t tile, frame_begin, frame_end;
-    if (P.items) {
+    if (!DIRECT) {
         const uint4 it = P.items[blockIdx.x];
         if (it.z == 0) return;  // unused slot of the over-sized grid
         tile = it.x;
@@ -403,7 +457,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     const size_t pix = (size_t)y * P.width + x;
     {
         float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (active && !P.items) acc = P.accum[pix];
+        if (active && DIRECT) acc = P.accum[pix];
         lds_acc[lane] = acc;
     }
 
@@ -496,53 +550,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 if (!need_new) {
-                    const HitRecord h = make_record(sc, cur, w.rec);
+                    uint32_t prim;
+                    path_done = shade_ray<STATS, GIZMO>(sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
                     if (want_aov) {
-                        P.aov_prim[pix] = h.prim;
-                        P.aov_t[pix] = h.hit ? h.t : 0.0f;
+                        P.aov_prim[pix] = prim;
+                        P.aov_t[pix] = w.rec.hit ? w.rec.t : 0.0f;
                         want_aov = false;
-                    }
-                    if (!h.hit) {
-                        // compute.wgsl:140-143
-                        if (STATS) cn.sky++;
-                        result = color * sky_lookup(sc, cur.d);
-                        path_done = true;
-                    } else {
-                        if (STATS) cn.bounces++;
-                        const v3 dir = normalize3(cur.d);
-                        v3 bdir = dir;
-                        const uint32_t m = material_u32(h.material);
-                        if (m == 1u) {
-                            bdir = reflect_dir(dir, h.normal);
-                        } else if (m == 2u) {
-                            const float ri = h.front ? kRefrFront : kRefrBack;
-                            const float cos_t = pt_min(dot3(-dir, h.normal), 1.0f);
-                            const float sin_t = pt_sqrt(pt_fma(-cos_t, cos_t, 1.0f));
-                            const bool cannot = ri * sin_t > 1.0f;
-                            if (cannot || reflectance(cos_t, h.front) > pt_hash_rand(h.p.x, h.p.y)) bdir = reflect_dir(dir, h.normal);
-                            else bdir = refract_dir(dir, h.normal, ri);
-                        } else if (GIZMO && m == 3u) {
-                            const float dn = dot3(initial_d, h.normal);
-                            if (bounce == 0 && dn <= 0.2f && dn >= -0.2f) {
-                                result = h.att;
-                                path_done = true;
-                            }
-                            limit++;  // correction, compute.wgsl:193
-                        } else {
-                            bdir = scatter_dir(dir, h.normal, seed);
-                        }
-                        if (m <= 1u && dot3(bdir, h.normal) <= 0.0f) {
-                            // compute.wgsl:151-153, 161-163: absorbed ray still sees the sky along the incoming ray
-                            if (STATS) cn.sky++;
-                            result = (color * h.att) * sky_lookup(sc, cur.d);
-                            path_done = true;
-                        }
-                        if (!path_done) {
-                            if (m != 3u) color = color * h.att;
-                            cur.o = h.p;
-                            cur.d = bdir;
-                            bounce++;
-                        }
                     }
                 }
                 advance(path_done, result);
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #endif
     }
 
-    if (P.items) P.partial[(size_t)blockIdx.x * 64u + lane] = lds_acc[lane];  // zeros for lanes outside the image
+    if (!DIRECT) P.partial[(size_t)blockIdx.x * 64u + lane] = lds_acc[lane];  // zeros for lanes outside the image
     else if (in_image) P.accum[pix] = lds_acc[lane];
 
     // Deterministic cost estimate (loop trips, a shading pass weighted like eight node visits), so
@@ -793,16 +806,17 @@ static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool o
 {
     const dim3 grid(n_blocks, 1, 1), block(PT_TRACE_BLOCK, 1, 1);
     static const size_t lds_pad = getenv("PTRT_LDS_PAD") ? (size_t)atoi(getenv("PTRT_LDS_PAD")) : 0;  // tuning aid: lowers occupancy
-#define PT_LAUNCH(ST, OV, GZ, S1) hipLaunchKernelGGL((trace_kernel<ST, OV, GZ, S1>), grid, block, lds_pad, stream, p)
-#define PT_LAUNCH_OV(OV)                                                      \
+#define PT_LAUNCH(ST, OV, GZ, S1, DI) hipLaunchKernelGGL((trace_kernel<ST, OV, GZ, S1, DI>), grid, block, lds_pad, stream, p)
+#define PT_LAUNCH_DI(OV, DI)                                                  \
     do {                                                                      \
-        if (detailed_stats) PT_LAUNCH(true, OV, true, false);                 \
-        else if (p.has_gizmo) { if (p.spp == 1) PT_LAUNCH(false, OV, true, true); else PT_LAUNCH(false, OV, true, false); } \
-        else { if (p.spp == 1) PT_LAUNCH(false, OV, false, true); else PT_LAUNCH(false, OV, false, false); } \
+        if (detailed_stats) PT_LAUNCH(true, OV, true, false, DI);             \
+        else if (p.has_gizmo) { if (p.spp == 1) PT_LAUNCH(false, OV, true, true, DI); else PT_LAUNCH(false, OV, true, false, DI); } \
+        else { if (p.spp == 1) PT_LAUNCH(false, OV, false, true, DI); else PT_LAUNCH(false, OV, false, false, DI); } \
     } while (0)
-    if (overflow) PT_LAUNCH_OV(true);
-    else PT_LAUNCH_OV(false);
-#undef PT_LAUNCH_OV
+    const bool direct = p.items == nullptr;
+    if (overflow) { if (direct) PT_LAUNCH_DI(true, true); else PT_LAUNCH_DI(true, false); }
+    else { if (direct) PT_LAUNCH_DI(false, true); else PT_LAUNCH_DI(false, false); }
+#undef PT_LAUNCH_DI
 #undef PT_LAUNCH
     return hipGetLastError();
 }

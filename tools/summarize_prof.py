@@ -13,6 +13,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r.get("Kernel_Name", "")]
     if rows:
+        print("== trace_kernel dispatches (ms): " + ", ".join("%s %.2f" % ("planned" if r["Kernel_Name"].rstrip(">)(PtTraceParams ").endswith("false") else "direct", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in rows))
         r = rows[-1]
         print("== last trace_kernel dispatch: VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s dur_ns=%d" % (
             r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"),
@@ -36,7 +37,7 @@ vals = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     xs = []
     for f in glob.glob(os.path.join(root, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
-        xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "trace_kernel<false" in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
+        xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "trace_kernel<false" in r.get("Kernel_Name", "") and "false>" in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
     big = [x for x in xs if x > 0.5 * max(xs)] if xs else []
     vals[name] = sum(big) / len(big) if big else None
 if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
