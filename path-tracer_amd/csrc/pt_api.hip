@@ -58,7 +58,7 @@ struct pt_ctx {
     uint32_t gstack_cap = 0;
 
     // work-item planning (see plan_kernel)
-    uint32_t *tile_cost = nullptr, *tile_sorted = nullptr;
+    uint32_t *tile_cost = nullptr, *tile_sorted = nullptr, *next_item = nullptr;
     uint2 *tile_items = nullptr;
     uint4 *items = nullptr;
     float4 *partial = nullptr;
@@ -210,6 +210,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     const size_t n_tiles = pt_trace_num_tiles(width, height);
     ctx->n_tiles = (uint32_t)n_tiles;
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_cost, n_tiles * sizeof(uint32_t)), "tile cost");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->next_item, 256), "item counter");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sorted, n_tiles * sizeof(uint32_t)), "tile order");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_items, n_tiles * sizeof(uint2)), "tile items");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
@@ -248,6 +249,7 @@ void pt_destroy(pt_ctx *ctx)
     dev_free(ctx->partial);
     dev_free(ctx->items);
     dev_free(ctx->tile_cost);
+    dev_free(ctx->next_item);
     dev_free(ctx->tile_sorted);
     dev_free(ctx->tile_items);
     dev_free(ctx->scratch);
@@ -497,6 +499,16 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
+    sch.use_pool = false;
+    if (const char *env = getenv("PTRT_POOL")) sch.use_pool = atoi(env) != 0;  // tuning aid
+    sch.next_item = ctx->next_item;
+    sch.pool_groups = ctx->resident_waves / PT_TRACE_WAVES_PER_EU;  // 4 waves per SIMD = 4 groups per CU
+    if (const char *env = getenv("PTRT_POOL_GROUPS")) sch.pool_groups = (uint32_t)atoi(env);  // tuning aid
+    p.pool_start = 24;
+    if (const char *env = getenv("PTRT_POOL_START")) p.pool_start = (uint32_t)atoi(env);  // tuning aid
+    p.pool_steps = 4;
+    if (const char *env = getenv("PTRT_POOL_STEPS")) p.pool_steps = (uint32_t)atoi(env);  // tuning aid
+    p.max_idle = 1u << 22;
 
     // the per-lane ray counter is 32 bits: bound the frames of one launch
     const uint64_t per_frame = (uint64_t)ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);

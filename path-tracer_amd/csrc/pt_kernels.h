@@ -55,6 +55,12 @@ struct PtTraceParams {
     unsigned long long *counters;  // PT_NUM_COUNTERS
     uint32_t *gstack;              // global-memory traversal stack (deep trees only)
     uint32_t gstack_cap;
+    // pooled kernel only (filled in by pt_launch_trace)
+    uint32_t *next_item;           // work-item counter, zero at launch
+    uint32_t n_items;
+    uint32_t pool_start;           // a shading wave starts walking once this many rays of its group are pending
+    uint32_t pool_steps;           // node visits per loop trip
+    uint32_t max_idle;             // consecutive idle trips after which a wave gives up
 };
 
 // Scheduling state owned by the context; every pointer is device memory.
@@ -70,6 +76,9 @@ struct PtSchedule {
     uint32_t default_chunk;       // frames per item when there is no measurement to plan from
     uint32_t min_planned_frames;  // shorter launches run one item per tile (exact sequential sums)
     uint32_t probe_frames;        // frames rendered directly to obtain the first measurement
+    bool use_pool;                // pooled kernel (persistent workgroups sharing their BVH walks through LDS)
+    uint32_t *next_item;          // one device word for the pooled kernel's item counter
+    uint32_t pool_groups;         // workgroups the pooled kernel is launched with (resident capacity)
 };
 
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).

@@ -228,6 +228,29 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     return false;
 }
 
+// walk_begin for the pooled kernel: same spheres + root visit, but the far child (if it has to be
+// visited) is returned in k2 instead of being pushed, because the walk may run on another lane.
+template <bool STATS>
+__device__ __forceinline__ bool walk_begin_pool(const PtDeviceScene &sc, const Ray &ray, Walk &w, uint32_t &k2_out, Counters &cn)
+{
+    struct OneSlot {
+        uint32_t v;
+        bool used;
+        __device__ __forceinline__ void push(uint32_t, uint32_t x) { v = x; used = true; }
+        __device__ __forceinline__ uint32_t pop(uint32_t) { return v; }
+    };
+    struct Ref {
+        OneSlot *p;
+        __device__ __forceinline__ void push(uint32_t sp, uint32_t x) { p->push(sp, x); }
+        __device__ __forceinline__ uint32_t pop(uint32_t sp) { return p->pop(sp); }
+    };
+    OneSlot slot{0xFFFFFFFFu, false};
+    const bool need = walk_begin<STATS>(sc, ray, w, Ref{&slot}, cn);
+    k2_out = slot.used ? slot.v : 0xFFFFFFFFu;
+    // a root that is itself a leaf still needs its triangles tested
+    return need;
+}
+
 template <bool STATS, typename StackT>
 __device__ __forceinline__ Closest hit_scene(const PtDeviceScene &sc, const Ray &ray, StackT stack, Counters &cn)
 {
@@ -380,12 +403,12 @@ __device__ __forceinline__ bool shade_ray(const PtDeviceScene &sc, Ray &cur, con
         result = (color * h.att) * sky_lookup(sc, cur.d);
         path_done = true;
     }
-    if (!path_done) {
-        if (m != 3u) color = color * h.att;
-        cur.o = h.p;
-        cur.d = bdir;
-        bounce++;
-    }
+    // The bounce ray.  Written unconditionally: when the path ends here nobody reads cur, color or
+    // bounce again before the next path overwrites them.
+    if (m != 3u) color = color * h.att;
+    cur.o = h.p;
+    cur.d = bdir;
+    bounce++;
     return path_done;
 }
 
@@ -551,7 +574,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 if (!need_new) {
                     uint32_t prim;
+#ifdef PT_DEBUG_PIXEL
+                    if (x == 27 && y == 20) printf("C pre  b=%u o=%a %a %a d=%a %a %a hit=%d idx=%u t=%a seed=%a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)w.rec.hit, w.rec.index, w.rec.t, seed);
+#endif
                     path_done = shade_ray<STATS, GIZMO>(sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
+#ifdef PT_DEBUG_PIXEL
+                    if (x == 27 && y == 20) printf("C post b=%u o=%a %a %a d=%a %a %a done=%d col=%a %a %a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)path_done, color.x, color.y, color.z);
+#endif
                     if (want_aov) {
                         P.aov_prim[pix] = prim;
                         P.aov_t[pix] = w.rec.hit ? w.rec.t : 0.0f;
@@ -616,6 +645,397 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     // one atomic per wave and counter
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 1;  // paths are counted on the host
+    for (int k = 0; k < ncount; k++) {
+        if (k == 1) continue;
+        const uint32_t s = wave_sum(vals[k]);
+        if (lane == 0 && s) atomicAdd(&P.counters[k], (unsigned long long)s);
+    }
+}
+
+// ---- the pooled megakernel -----------------------------------------------------------------
+// Same per-ray arithmetic as trace_kernel, different division of labour.  In an outdoor scene only
+// about one ray in ten needs a real BVH walk, so a wave that walks its own rays steps ~10 live lanes
+// out of 64.  Here a workgroup of PT_POOL_WAVES waves pools its walks through LDS:
+//   * every lane OWNS one pixel of its wave's work item (path state, RNG, sums) and, separately, has
+//     a WALK SLOT that can carry any ray of the workgroup;
+//   * an owner whose new ray survives the root visit parks it in its LDS "box" and posts its thread
+//     id on its wave's ring (single producer); waves with free walk slots claim ring entries with a
+//     compare-and-swap on the ring head, load the ray from the owner's box and walk it; the closest
+//     hit goes back into the box and the owner shades it at its wave's next shading pass;
+//   * a wave starts walking only when enough rays are pending (or it has nothing else to do) and
+//     then keeps topping up, so the walks concentrate on few waves with well-filled lanes while the
+//     other waves only shade;
+//   * waves are persistent: when all 64 owners of a wave have finished their item the wave takes
+//     the next one from a global counter, and its walk slots keep serving the workgroup meanwhile.
+// LDS per workgroup: stacks [entry][thread] (24 KiB), boxes [field][thread] (12 KiB), rings.
+#define PT_POOL_WAVES 4
+#define PT_POOL_THREADS (64 * PT_POOL_WAVES)
+#define PT_POOL_STACK PT_LDS_STACK
+#ifndef PT_POOL_WAVES_PER_EU
+#define PT_POOL_WAVES_PER_EU 4  // 128 VGPRs: owner state and walk slot side by side
+#endif
+enum : uint32_t { BOX_OX, BOX_OY, BOX_OZ, BOX_DX, BOX_DY, BOX_DZ, BOX_T, BOX_ID, BOX_U_NODE, BOX_V_NODE2, BOX_STATUS, BOX_STEPS, BOX_FIELDS };
+enum : uint32_t { BOX_EMPTY = 0, BOX_PENDING = 1, BOX_DONE = 2 };
+
+struct PoolShared {
+    uint32_t stack[PT_POOL_STACK][PT_POOL_THREADS];
+    uint32_t box[BOX_FIELDS][PT_POOL_THREADS];
+    uint32_t ring[PT_POOL_WAVES][64];
+    uint32_t tail[PT_POOL_WAVES];  // written by the producing wave only
+    uint32_t head[PT_POOL_WAVES];  // advanced by consumers (compare-and-swap)
+    uint32_t waves_done;
+};
+
+template <bool OVERFLOW>
+struct PoolStack {
+    uint32_t *lds;   // &sh.stack[0][tid]
+    uint32_t *spill;
+    size_t pitch;
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
+    {
+        if (!OVERFLOW || sp < PT_POOL_STACK) lds[sp * PT_POOL_THREADS] = v;
+        else spill[(size_t)(sp - PT_POOL_STACK) * pitch] = v;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp)
+    {
+        if (!OVERFLOW || sp < PT_POOL_STACK) return lds[sp * PT_POOL_THREADS];
+        return spill[(size_t)(sp - PT_POOL_STACK) * pitch];
+    }
+};
+
+// Hand-shake words are accessed with relaxed workgroup-scope atomics (plain ds_read/ds_write that the
+// compiler neither caches nor reorders across the fences around them).
+__device__ __forceinline__ uint32_t lds_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1, bool DIRECT>
+__global__ __launch_bounds__(PT_POOL_THREADS, PT_POOL_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
+{
+    __shared__ PoolShared sh;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const PtDeviceScene &sc = P.sc;
+    const bool primary = wv == ((blockIdx.x >> 3) & (PT_POOL_WAVES - 1u));
+    if (tid < PT_POOL_WAVES) { sh.tail[tid] = 0; sh.head[tid] = 0; }
+    if (tid == 0) sh.waves_done = 0;
+    sh.box[BOX_STATUS][tid] = BOX_EMPTY;
+    __syncthreads();
+
+    PoolStack<OVERFLOW> stack{&sh.stack[0][tid], nullptr, 0};
+    if (OVERFLOW) {
+        stack.spill = P.gstack + ((size_t)blockIdx.x * PT_POOL_THREADS + tid);
+        stack.pitch = (size_t)gridDim.x * PT_POOL_THREADS;
+    }
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- owner side ----
+    enum : uint32_t { O_DONE = 0, O_READY = 1, O_WAIT = 2 };
+    uint32_t ostate = O_DONE;
+    bool have_item = false, out_of_items = false;
+    uint32_t item_index = 0, tile = 0, frame = 0, frame_end = 0, x = 0, y = 0;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t sample = 0, sx = 0, sy = 0, sz = 0, sw = 0;
+    v3 frame_sum = V3(0.0f, 0.0f, 0.0f), initial_d = V3(0.0f, 0.0f, 0.0f), color = V3(1.0f, 1.0f, 1.0f);
+    float seed = 0.0f;
+    uint32_t bounce = 0, limit = 0, cost = 0;
+    bool have_ray = false, want_aov = false, in_image = false;
+    uint32_t my_tail = 0;  // this wave's ring tail (only this wave writes it)
+
+    // ---- walk slot ----
+    bool wbusy = false;
+    uint32_t wowner = 0, wsteps = 0;
+    Ray wray;
+    wray.o = wray.d = V3(0.0f, 0.0f, 0.0f);
+    Walk w;
+    w.rec.hit = w.rec.is_tri = false;
+    w.rec.t = w.rec.u = w.rec.v = 0.0f;
+    w.rec.index = 0;
+    w.inv = V3(0.0f, 0.0f, 0.0f);
+    w.nearest = 9999.0f;
+    w.node = 0;
+    w.sp = 0;
+
+    // Every wave leaves the loop: normally when all waves of the group have run out of items, and
+    // in any case after max_idle consecutive trips without anything to do (a lost hand-shake would
+    // otherwise hang the GPU; the check after the loop reports it).
+#ifdef PT_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dg_trips = 0, dg_idle = 0, dg_shades = 0, dg_ready = 0, dg_shade_cyc = 0, dg_steps = 0, dg_busy = 0, dg_walk_cyc = 0,
+                       dg_claim_cyc = 0, dg_claims = 0, dg_s = 0;
+#endif
+    for (uint32_t idle = 0; idle < P.max_idle;) {
+        bool did_work = false;
+#ifdef PT_DIAG
+        dg_trips++;
+#endif
+
+        // (a) item hand-over: all 64 owners finished -> write the sums out, take the next item
+        if (__ballot(ostate != O_DONE) == 0ull && !out_of_items) {
+            if (have_item) {
+                if (!DIRECT) P.partial[(size_t)item_index * 64u + lane] = acc;
+                else if (in_image) P.accum[(size_t)y * P.width + x] = acc;
+                const uint32_t c = wave_sum(cost);
+                if (P.cost && lane == 0) atomicAdd(&P.cost[tile], c);
+                have_item = false;
+            }
+            uint32_t fb = 0, fc = 0;
+            for (;;) {
+                uint32_t it = 0;
+                if (lane == 0) it = atomicAdd(P.next_item, 1u);
+                it = __builtin_amdgcn_readfirstlane(it);
+                if (it >= P.n_items) { out_of_items = true; break; }
+                if (DIRECT) { tile = it; fb = 0; fc = P.n_frames; }
+                else { const uint4 rec = P.items[it]; tile = rec.x; fb = rec.y; fc = rec.z; }
+                if (fc != 0) { item_index = it; have_item = true; break; }
+            }
+            if (out_of_items) {
+                if (lane == 0) atomicAdd(&sh.waves_done, 1u);
+            } else {
+                const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+                x = tbx * PT_TILE + (lane & 7u);
+                y = tby * PT_TILE + (lane >> 3);
+                in_image = (x < P.cols) && (y < P.rows) && P.spp > 0;
+                frame = fb;
+                frame_end = fb + fc;
+                sample = 0;
+                frame_sum = V3(0.0f, 0.0f, 0.0f);
+                cost = 0;
+                have_ray = false;
+                acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (DIRECT && in_image) acc = P.accum[(size_t)y * P.width + x];
+                ostate = in_image ? O_READY : O_DONE;
+                did_work = true;
+            }
+        }
+
+        // (b) owners whose walk came back
+        if (ostate == O_WAIT && lds_load(&sh.box[BOX_STATUS][tid]) == BOX_DONE) ostate = O_READY;
+
+        // wave-uniform view of the pool
+        uint32_t avail_total = 0;
+        for (uint32_t s2 = 0; s2 < PT_POOL_WAVES; s2++) avail_total += lds_load(&sh.tail[s2]) - lds_load(&sh.head[s2]);
+        const unsigned long long ready = __ballot(ostate == O_READY);
+        const uint32_t nready = (uint32_t)__popcll(ready);
+        const bool walking_any = __ballot(wbusy) != 0ull;
+
+        // (c) shading pass: worth it with enough ready owners, or when there is nothing else to do
+        if (nready >= P.refill_lanes || (nready > 0 && !walking_any && avail_total == 0)) {
+            did_work = true;
+            bool post = false;
+#ifdef PT_DIAG
+            dg_shades++;
+            dg_ready += nready;
+            dg_s = clock64();
+#endif
+            if (ostate == O_READY) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                bool path_done = false;
+                v3 result = V3(0.0f, 0.0f, 0.0f);
+                Ray cur;
+                cur.o = cur.d = V3(0.0f, 0.0f, 0.0f);
+                if (have_ray) {
+                    cur.o = V3(__uint_as_float(sh.box[BOX_OX][tid]), __uint_as_float(sh.box[BOX_OY][tid]), __uint_as_float(sh.box[BOX_OZ][tid]));
+                    cur.d = V3(__uint_as_float(sh.box[BOX_DX][tid]), __uint_as_float(sh.box[BOX_DY][tid]), __uint_as_float(sh.box[BOX_DZ][tid]));
+                    Closest c;
+                    const uint32_t id = sh.box[BOX_ID][tid];
+                    c.hit = (id >> 31) != 0;
+                    c.is_tri = ((id >> 30) & 1u) != 0;
+                    c.index = id & 0x3FFFFFFFu;
+                    c.t = __uint_as_float(sh.box[BOX_T][tid]);
+                    c.u = __uint_as_float(sh.box[BOX_U_NODE][tid]);
+                    c.v = __uint_as_float(sh.box[BOX_V_NODE2][tid]);
+                    cost += 4u + sh.box[BOX_STEPS][tid];
+                    uint32_t prim;
+#ifdef PT_DEBUG_PIXEL
+                    if (x == 27 && y == 20) printf("P pre  b=%u o=%a %a %a d=%a %a %a hit=%d idx=%u t=%a seed=%a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)c.hit, c.index, c.t, seed);
+#endif
+                    path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
+#ifdef PT_DEBUG_PIXEL
+                    if (x == 27 && y == 20) printf("P post b=%u o=%a %a %a d=%a %a %a done=%d col=%a %a %a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)path_done, color.x, color.y, color.z);
+#endif
+                    if (want_aov) {
+                        P.aov_prim[(size_t)y * P.width + x] = prim;
+                        P.aov_t[(size_t)y * P.width + x] = c.hit ? c.t : 0.0f;
+                        want_aov = false;
+                    }
+                }
+                // retire finished paths, start new ones (compute.wgsl:112-128)
+                bool active = true;
+                while (active && (!have_ray || path_done || bounce >= limit)) {
+                    if (have_ray) {
+                        const v3 path_color = path_done ? result : color;
+                        path_done = false;
+                        if (!SPP1) { frame_sum = frame_sum + path_color; sample++; }
+                        if (SPP1 || sample == P.spp) {
+                            const v3 mean = (SPP1 ? path_color : frame_sum) * P.inv_spp;
+                            acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                            frame_sum = V3(0.0f, 0.0f, 0.0f);
+                            sample = 0;
+                            frame++;
+                            if (frame == frame_end) { active = false; break; }
+                        }
+                    }
+                    if (sample == 0) {
+                        const uint32_t time = P.time0 + frame * P.stride;  // compute.wgsl:85
+                        sx = x; sy = y; sz = x + time; sw = y + time;
+                    }
+                    const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                    const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                    const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
+                    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
+                    cur.o = P.fr.origin;
+                    cur.d = (ploc + smp) - P.fr.origin;
+                    if (GIZMO) initial_d = cur.d;
+                    color = V3(1.0f, 1.0f, 1.0f);
+                    seed = pt_hybrid_taus(sx, sy, sz, sw);
+                    bounce = 0;
+                    limit = P.depth;
+                    have_ray = true;
+                    want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
+                }
+                if (!active) {
+                    ostate = O_DONE;
+                } else {
+                    cn.rays++;
+                    // spheres + root visit; a surviving ray is parked in the box for a walk slot
+                    Walk nw;
+                    uint32_t k2 = 0xFFFFFFFFu;
+                    const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
+                    sh.box[BOX_OX][tid] = __float_as_uint(cur.o.x); sh.box[BOX_OY][tid] = __float_as_uint(cur.o.y); sh.box[BOX_OZ][tid] = __float_as_uint(cur.o.z);
+                    sh.box[BOX_DX][tid] = __float_as_uint(cur.d.x); sh.box[BOX_DY][tid] = __float_as_uint(cur.d.y); sh.box[BOX_DZ][tid] = __float_as_uint(cur.d.z);
+                    sh.box[BOX_T][tid] = __float_as_uint(nw.rec.t);
+                    sh.box[BOX_ID][tid] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
+                    sh.box[BOX_U_NODE][tid] = need_walk ? nw.node : 0u;
+                    sh.box[BOX_V_NODE2][tid] = need_walk ? k2 : 0u;
+                    sh.box[BOX_STEPS][tid] = 0u;
+                    lds_store(&sh.box[BOX_STATUS][tid], need_walk ? BOX_PENDING : BOX_DONE);
+                    ostate = need_walk ? O_WAIT : O_READY;
+                    post = need_walk;
+                }
+            }
+            const unsigned long long posting = __ballot(post);
+            if (posting) {
+                if (post) sh.ring[wv][(my_tail + (uint32_t)__popcll(posting & lt_mask)) & 63u] = tid;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                my_tail += (uint32_t)__popcll(posting);
+                if (lane == 0) lds_store(&sh.tail[wv], my_tail);
+                avail_total += (uint32_t)__popcll(posting);
+            }
+#ifdef PT_DIAG
+            dg_shade_cyc += clock64() - dg_s;
+#endif
+        }
+
+        // (d) claim pending rays for free walk slots
+#ifdef PT_DIAG
+        dg_s = clock64();
+#endif
+        unsigned long long free_mask = __ballot(!wbusy);
+        // One wave of the group (rotating with the group index so that the walkers of a CU spread over
+        // its SIMDs) takes every pending ray it has room for; the others join in only when rays pile
+        // up or when none of their owners can be shaded.
+        if (free_mask && avail_total && (primary || avail_total >= P.pool_start || __ballot(ostate == O_READY) == 0ull)) {
+            for (uint32_t s2 = 0; s2 < PT_POOL_WAVES && free_mask; s2++) {
+                const uint32_t src = (wv + s2) & (PT_POOL_WAVES - 1u);
+                const uint32_t hd = lds_load(&sh.head[src]);
+                const uint32_t avail = lds_load(&sh.tail[src]) - hd;
+                if (avail == 0 || avail > 64u) continue;
+                const uint32_t n = min(avail, (uint32_t)__popcll(free_mask));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // read the entries first, claim them second: if the claim succeeds the head had not
+                // moved, so the entries were unclaimed (and their owners parked) while they were read
+                const uint32_t rank = (uint32_t)__popcll(free_mask & lt_mask);
+                const uint32_t o = lds_load(&sh.ring[src][(hd + rank) & 63u]);
+                uint32_t ok = 0;
+                if (lane == 0) ok = atomicCAS(&sh.head[src], hd, hd + n) == hd ? 1u : 0u;
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                if (!ok) continue;
+                if (!wbusy && rank < n) {
+                    wowner = o;
+                    wray.o = V3(__uint_as_float(sh.box[BOX_OX][o]), __uint_as_float(sh.box[BOX_OY][o]), __uint_as_float(sh.box[BOX_OZ][o]));
+                    wray.d = V3(__uint_as_float(sh.box[BOX_DX][o]), __uint_as_float(sh.box[BOX_DY][o]), __uint_as_float(sh.box[BOX_DZ][o]));
+                    const uint32_t id = sh.box[BOX_ID][o];
+                    w.rec.hit = (id >> 31) != 0;
+                    w.rec.is_tri = false;
+                    w.rec.index = id & 0x3FFFFFFFu;
+                    w.rec.t = __uint_as_float(sh.box[BOX_T][o]);
+                    w.rec.u = w.rec.v = 0.0f;
+                    w.inv = V3(1.0f / wray.d.x, 1.0f / wray.d.y, 1.0f / wray.d.z);
+                    w.nearest = 9999.0f;
+                    w.node = sh.box[BOX_U_NODE][o];
+                    w.sp = 0;
+                    const uint32_t k2 = sh.box[BOX_V_NODE2][o];
+                    if (k2 != 0xFFFFFFFFu) stack.push(w.sp++, k2);
+                    wsteps = 0;
+                    wbusy = true;
+                }
+                free_mask = __ballot(!wbusy);
+                did_work = true;
+#ifdef PT_DIAG
+                dg_claims += n;
+#endif
+            }
+        }
+#ifdef PT_DIAG
+        dg_claim_cyc += clock64() - dg_s;
+        dg_s = clock64();
+#endif
+
+        // (e) step the walkers a few node visits
+        for (uint32_t k = 0; k < P.pool_steps && __ballot(wbusy) != 0ull; k++) {
+            did_work = true;
+#ifdef PT_DIAG
+            dg_steps++;
+            dg_busy += __popcll(__ballot(wbusy));
+#endif
+            if (wbusy) {
+                wsteps++;
+                if (walk_step<STATS>(sc, wray, w, stack, cn)) {
+                    sh.box[BOX_T][wowner] = __float_as_uint(w.rec.t);
+                    sh.box[BOX_ID][wowner] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
+                    sh.box[BOX_U_NODE][wowner] = __float_as_uint(w.rec.u);
+                    sh.box[BOX_V_NODE2][wowner] = __float_as_uint(w.rec.v);
+                    sh.box[BOX_STEPS][wowner] = wsteps;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lds_store(&sh.box[BOX_STATUS][wowner], BOX_DONE);
+                    wbusy = false;
+                }
+            }
+        }
+
+#ifdef PT_DIAG
+        dg_walk_cyc += clock64() - dg_s;
+        if (!did_work) dg_idle++;
+#endif
+        if (lds_load(&sh.waves_done) == PT_POOL_WAVES) break;
+        if (did_work) {
+            idle = 0;
+        } else {
+            idle++;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+
+#ifdef PT_DIAG
+    {
+        const uint32_t wid = blockIdx.x * PT_POOL_WAVES + wv;
+        if (lane == 0 && wid < PT_DIAG_MAX_WAVES) {
+            g_diag[8 * wid + 0] = diag_t0;
+            g_diag[8 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+            g_diag[8 * wid + 2] = dg_trips | (dg_idle << 32);
+            g_diag[8 * wid + 3] = dg_shades | (dg_ready << 32);
+            g_diag[8 * wid + 4] = dg_shade_cyc;
+            g_diag[8 * wid + 5] = dg_steps | (dg_busy << 32);
+            g_diag[8 * wid + 6] = dg_walk_cyc;
+            g_diag[8 * wid + 7] = dg_claim_cyc | (dg_claims << 40);
+        }
+    }
+#endif
+    // a wave that ran out of trips (should never happen) leaves a mark instead of hanging the GPU
+    if (__ballot(ostate != O_DONE || wbusy) != 0ull && lane == 0) atomicAdd(&P.counters[PT_NUM_COUNTERS - 1], 1ull << 48);
+
+    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
+    const int ncount = STATS ? PT_NUM_COUNTERS : 1;
     for (int k = 0; k < ncount; k++) {
         if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
@@ -821,6 +1241,28 @@ static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool o
     return hipGetLastError();
 }
 
+// Pooled variant: a fixed grid of persistent workgroups that take items from *p.next_item.
+static hipError_t launch_pool(PtTraceParams p, uint32_t n_items, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(sch.next_item, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    p.next_item = sch.next_item;
+    p.n_items = n_items;
+    const uint32_t groups = std::max(1u, std::min(sch.pool_groups, (n_items + PT_POOL_WAVES - 1u) / PT_POOL_WAVES));
+    const dim3 grid(groups, 1, 1), block(PT_POOL_THREADS, 1, 1);
+#define PT_LAUNCH(ST, GZ, S1, DI) hipLaunchKernelGGL((pool_kernel<ST, false, GZ, S1, DI>), grid, block, 0, stream, p)
+#define PT_LAUNCH_DI(DI)                                                  \
+    do {                                                                  \
+        if (detailed_stats) PT_LAUNCH(true, true, false, DI);             \
+        else if (p.has_gizmo) { if (p.spp == 1) PT_LAUNCH(false, true, true, DI); else PT_LAUNCH(false, true, false, DI); } \
+        else { if (p.spp == 1) PT_LAUNCH(false, false, true, DI); else PT_LAUNCH(false, false, false, DI); } \
+    } while (0)
+    if (p.items == nullptr) PT_LAUNCH_DI(true); else PT_LAUNCH_DI(false);
+#undef PT_LAUNCH_DI
+#undef PT_LAUNCH
+    return hipGetLastError();
+}
+
 uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height)
 {
     return ((width + PT_TILE - 1u) / PT_TILE) * ((height + PT_TILE - 1u) / PT_TILE);
@@ -844,10 +1286,12 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     p.cost = nullptr;
     // Few frames, no scheduling buffers, or a spilling stack (whose buffer has one column per tile
     // lane): one item per tile, frames added in order onto the stored sums.
+    const bool pool = sch.use_pool && sch.next_item && !overflow;
     const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost || overflow;
     if (direct) {
         p.items = nullptr;
         p.partial = nullptr;
+        if (pool) return launch_pool(p, p.n_tiles, detailed_stats, sch, stream);
         return launch_items(p, p.n_tiles, overflow, detailed_stats, stream);
     }
     hipError_t e;
@@ -858,7 +1302,8 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
         first.partial = nullptr;
         first.n_frames = std::min(p.n_frames, sch.probe_frames);
         first.cost = sch.cost;
-        if ((e = launch_items(first, p.n_tiles, overflow, detailed_stats, stream)) != hipSuccess) return e;
+        e = pool ? launch_pool(first, p.n_tiles, detailed_stats, sch, stream) : launch_items(first, p.n_tiles, overflow, detailed_stats, stream);
+        if (e != hipSuccess) return e;
         *sch.cost_valid = true;
         p.time0 += first.n_frames * p.stride;
         p.n_frames -= first.n_frames;
@@ -873,7 +1318,8 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     p.items = sch.items;
     p.partial = sch.partial;
     p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
-    if ((e = launch_items(p, cap, overflow, detailed_stats, stream)) != hipSuccess) return e;
+    e = pool ? launch_pool(p, cap, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
                        sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
     return hipGetLastError();

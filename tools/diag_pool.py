@@ -1,0 +1,50 @@
+"""Diagnostic (GPU box): per-wave section counters of the pooled kernel from the PT_DIAG build.
+Run: PTRT_POOL=1 PTRT_LIB=path-tracer_amd/libptrt_diag.so python tools/diag_pool.py [frames]"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _pkgload
+
+pt = _pkgload.load()
+scenes = importlib.import_module("path_tracer_amd.scenes")
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+scene, w, h, st = scenes.CONFIGS["bunny_1080p_d8_spp256"][0](), 1920, 1080, pt.Settings(1, 8, 1e-4, 1000.0)
+r = pt.Renderer(scene, w, h, settings=st)
+r.set_sky_equirect(scenes.sky_equirect(4096, 2048), 4096)
+L = pt.lib()
+L.pt_diag_clear.argtypes = []
+L.pt_diag_read.argtypes = [C.c_void_p, C.c_size_t]
+r.render_frames(1, 1, frames); r.sync()
+r.reset_ready_samples()
+L.pt_diag_clear()
+r.render_frames(1, 1, frames); r.sync()
+rays = r.stats()["rays"]
+buf = np.zeros((1 << 18, 8), np.uint64)
+assert L.pt_diag_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+buf = buf[buf[:, 1] > 0]
+M32 = np.uint64(0xFFFFFFFF)
+t0, t1 = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64)
+trips, idle = (buf[:, 2] & M32).astype(np.float64), (buf[:, 2] >> np.uint64(32)).astype(np.float64)
+shades, ready = (buf[:, 3] & M32).astype(np.float64), (buf[:, 3] >> np.uint64(32)).astype(np.float64)
+shade_cyc = buf[:, 4].astype(np.float64)
+steps, busy = (buf[:, 5] & M32).astype(np.float64), (buf[:, 5] >> np.uint64(32)).astype(np.float64)
+walk_cyc = buf[:, 6].astype(np.float64)
+claim_cyc, claims = (buf[:, 7] & np.uint64((1 << 40) - 1)).astype(np.float64), (buf[:, 7] >> np.uint64(40)).astype(np.float64)
+span = (t1.max() - t0.min()) / 100.0
+dur = (t1 - t0) / 100.0
+print(f"waves {len(buf)} span {span:.0f} us; wave duration p50 {np.median(dur):.0f} max {dur.max():.0f} us; rays (this launch incl. earlier) {rays}")
+tot = shade_cyc.sum() + walk_cyc.sum() + claim_cyc.sum()
+print("cycle shares: shade %.1f%% walk %.1f%% claim %.1f%%" % (100 * shade_cyc.sum() / tot, 100 * walk_cyc.sum() / tot, 100 * claim_cyc.sum() / tot))
+print("trips/wave %.0f, idle trips %.1f%%" % (trips.mean(), 100 * idle.sum() / trips.sum()))
+print("shading passes/wave %.0f, mean ready lanes %.1f, cycles per pass %.0f" % (shades.mean(), ready.sum() / shades.sum(), shade_cyc.sum() / shades.sum()))
+print("walk steps/wave %.0f, mean busy lanes %.1f, cycles per step %.0f" % (steps.mean(), busy.sum() / max(steps.sum(), 1), walk_cyc.sum() / max(steps.sum(), 1)))
+print("claims/wave %.0f, claim cycles per trip %.0f" % (claims.mean(), claim_cyc.sum() / trips.sum()))
+ws = steps.reshape(-1, 4) if len(steps) % 4 == 0 else None
+if ws is not None:
+    srt = np.sort(ws, axis=1)[:, ::-1]
+    print("walk steps by rank within the group (most-walking wave first): " + " ".join(f"{v:.0f}" for v in srt.mean(axis=0)))
