@@ -56,6 +56,9 @@ struct pt_ctx {
     uint32_t *gstack = nullptr;
     size_t gstack_bytes = 0;
     uint32_t gstack_cap = 0;
+    uint32_t *pool_gstack = nullptr;
+    size_t pool_gstack_bytes = 0;
+    uint32_t n_cus = 256;
 
     // work-item planning (see plan_kernel)
     uint32_t *tile_cost = nullptr, *tile_sorted = nullptr, *next_item = nullptr;
@@ -217,7 +220,10 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        {
             ctx->resident_waves = (uint32_t)prop.multiProcessorCount * 4u * PT_TRACE_WAVES_PER_EU;
+            ctx->n_cus = (uint32_t)prop.multiProcessorCount;
+        }
     }
     if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
@@ -249,6 +255,7 @@ void pt_destroy(pt_ctx *ctx)
     dev_free(ctx->partial);
     dev_free(ctx->items);
     dev_free(ctx->tile_cost);
+    dev_free(ctx->pool_gstack);
     dev_free(ctx->next_item);
     dev_free(ctx->tile_sorted);
     dev_free(ctx->tile_items);
@@ -477,14 +484,25 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
     p.aov_t = ctx->aov_t;
     p.counters = ctx->counters;
-    const size_t gs = pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
+    bool use_pool = false;
+    if (const char *env = getenv("PTRT_POOL")) use_pool = atoi(env) != 0;  // tuning aid
+    // spill space for traversal stacks deeper than the kernels keep in LDS
+    const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
     if (gs) {
         int rc = ensure_gstack(ctx, gs);
         if (rc != PT_OK) return rc;
     }
     p.gstack = ctx->gstack;
     p.gstack_cap = gs ? ctx->bvh_depth : 0;
-    p.refill_lanes = 48;
+    const size_t pgs = use_pool ? pt_pool_gstack_bytes(ctx->n_cus, ctx->bvh_depth) : 0;
+    if (pgs > ctx->pool_gstack_bytes) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->pool_gstack);
+        ctx->pool_gstack_bytes = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->pool_gstack, pgs));
+        ctx->pool_gstack_bytes = pgs;
+    }
+    p.refill_lanes = use_pool ? 64 : 48;
     if (const char *env = getenv("PTRT_REFILL_LANES")) p.refill_lanes = (uint32_t)atoi(env);  // tuning aid
 
     PtSchedule sch{};
@@ -499,13 +517,20 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
-    sch.use_pool = false;
-    if (const char *env = getenv("PTRT_POOL")) sch.use_pool = atoi(env) != 0;  // tuning aid
+    sch.use_pool = use_pool;
     sch.next_item = ctx->next_item;
-    sch.pool_groups = ctx->resident_waves / PT_TRACE_WAVES_PER_EU;  // 4 waves per SIMD = 4 groups per CU
+    sch.pool_gstack = ctx->pool_gstack;
+    sch.n_cus = ctx->n_cus;
+    sch.pool_groups = 0;
     if (const char *env = getenv("PTRT_POOL_GROUPS")) sch.pool_groups = (uint32_t)atoi(env);  // tuning aid
-    p.pool_start = 24;
+    p.pool_start = 48;
     if (const char *env = getenv("PTRT_POOL_START")) p.pool_start = (uint32_t)atoi(env);  // tuning aid
+    p.pool_topup = 16;
+    if (const char *env = getenv("PTRT_POOL_TOPUP")) p.pool_topup = (uint32_t)atoi(env);  // tuning aid
+    p.pool_dense = 16;
+    if (const char *env = getenv("PTRT_POOL_DENSE")) p.pool_dense = (uint32_t)atoi(env);  // tuning aid
+    p.pool_shade_dense = 128;
+    if (const char *env = getenv("PTRT_POOL_SHADE_DENSE")) p.pool_shade_dense = (uint32_t)atoi(env);  // tuning aid
     p.pool_steps = 4;
     if (const char *env = getenv("PTRT_POOL_STEPS")) p.pool_steps = (uint32_t)atoi(env);  // tuning aid
     p.max_idle = 1u << 22;
@@ -521,7 +546,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         const uint32_t batch = std::min(n_frames - done, max_frames);
         p.time0 = time0 + done * stride;
         p.n_frames = batch;
-        if (batch >= sch.min_planned_frames && !gs) {
+        if (batch >= sch.min_planned_frames && (use_pool || !pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth))) {
             const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, sch);
             if (cap > ctx->item_cap) {
                 PT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -58,7 +58,10 @@ struct PtTraceParams {
     // pooled kernel only (filled in by pt_launch_trace)
     uint32_t *next_item;           // work-item counter, zero at launch
     uint32_t n_items;
-    uint32_t pool_start;           // a shading wave starts walking once this many rays of its group are pending
+    uint32_t pool_start;           // an idle wave starts walking once this many rays of its group are pending
+    uint32_t pool_topup;           // a walking wave takes more rays once this many of its walk slots are free
+    uint32_t pool_dense;           // walkers that make a wave "walking" in that sense
+    uint32_t pool_shade_dense;     // ready paths at which even a walking wave runs a shading pass
     uint32_t pool_steps;           // node visits per loop trip
     uint32_t max_idle;             // consecutive idle trips after which a wave gives up
 };
@@ -76,9 +79,11 @@ struct PtSchedule {
     uint32_t default_chunk;       // frames per item when there is no measurement to plan from
     uint32_t min_planned_frames;  // shorter launches run one item per tile (exact sequential sums)
     uint32_t probe_frames;        // frames rendered directly to obtain the first measurement
-    bool use_pool;                // pooled kernel (persistent workgroups sharing their BVH walks through LDS)
+    bool use_pool;                // pooled kernel (persistent workgroups, paths and rays pooled in LDS)
     uint32_t *next_item;          // one device word for the pooled kernel's item counter
-    uint32_t pool_groups;         // workgroups the pooled kernel is launched with (resident capacity)
+    uint32_t *pool_gstack;        // pt_pool_gstack_bytes() of spill space, null if the tree is shallow enough
+    uint32_t n_cus;               // compute units of the device
+    uint32_t pool_groups;         // workgroups to launch; 0 = as many as are resident at once
 };
 
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).
@@ -88,6 +93,8 @@ uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height);
 uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule &sch);
 // Bytes of global stack pt_launch_trace needs for this image/tree, 0 if the LDS stack suffices.
 size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth);
+// Same for the pooled kernel (PtSchedule::pool_gstack).
+size_t pt_pool_gstack_bytes(uint32_t n_cus, uint32_t stack_depth);
 
 struct PtRayQuery {
     PtDeviceScene sc;

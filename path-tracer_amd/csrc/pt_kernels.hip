@@ -228,6 +228,100 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     return false;
 }
 
+// The same walk in steps that each wait for memory only once: a step is one interior-node visit
+// or ONE triangle of a leaf, and every lane's loads (child pair or triangle) are issued together
+// before any of them is used, so a wave whose lanes are at interior nodes and at leaves pays one
+// memory latency per step instead of one per kind.  Node and triangle order are unchanged.
+struct WalkU : Walk {
+    uint32_t leaf_next;  // next triangle slot of the leaf being tested
+    uint32_t leaf_left;  // triangles of that leaf still to test (0: w.node is still to be visited)
+};
+
+// Call whenever w.node has been set: a leaf with an inline triangle count goes straight to
+// triangle mode.
+__device__ __forceinline__ void walk_enter(WalkU &w)
+{
+    const uint32_t count = (w.node >> 28) & 7u;
+    if ((w.node & PT_TOKEN_LEAF) && count != 0u) {
+        w.leaf_next = w.node & PT_TOKEN_LOW;
+        w.leaf_left = count;
+    }
+}
+
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn)
+{
+    const v3 o = ray.o, d = ray.d;
+    const bool tri = w.leaf_left != 0u;
+    bool next_node = false;
+    if (!tri && (w.node & PT_TOKEN_LEAF)) {
+        // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
+        const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
+        w.leaf_next = m.x;
+        w.leaf_left = m.y;
+        next_node = m.y == 0u;
+    } else {
+        const float4 *base = tri ? sc.tri_pos + 3 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
+        const float4 q0 = base[0], q1 = base[1], q2 = base[2];
+        float4 q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!tri) q3 = base[3];
+        if (!tri) {
+            if (STATS) cn.interior++;
+            float d1 = hit_aabb(o, w.inv, q0, q1);
+            float d2 = hit_aabb(o, w.inv, q2, q3);
+            uint32_t k1 = __float_as_uint(q0.w), k2 = __float_as_uint(q2.w);
+            if (d1 > d2) {
+                const float td = d1; d1 = d2; d2 = td;
+                const uint32_t tk = k1; k1 = k2; k2 = tk;
+            }
+            if (d1 > w.nearest) {
+                next_node = true;
+            } else {
+                w.node = k1;
+                if (d2 < w.nearest) stack.push(w.sp++, k2);
+            }
+        } else {
+            // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
+            const uint32_t slot = w.leaf_next;
+            w.leaf_next = slot + 1u;
+            w.leaf_left--;
+            next_node = w.leaf_left == 0u;
+            if (STATS) cn.tri_tests++;
+            const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
+            const v3 h = cross3(d, e2);
+            const float a = dot3(e1, h);
+            if (!(a > -0.00001f && a < 0.00001f)) {
+                const float f = 1.0f / a;
+                const v3 s = o - f4_xyz(q0);
+                const float u = f * dot3(s, h);
+                if (!(u < 0.0f || u > 1.0f)) {
+                    const v3 q = cross3(s, e1);
+                    const float v = f * dot3(d, q);
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        const float t = f * dot3(e2, q);
+                        if (!(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t)) {
+                            w.rec.hit = true;
+                            w.rec.is_tri = true;
+                            w.rec.t = t;
+                            w.rec.index = slot;
+                            w.rec.u = u;
+                            w.rec.v = v;
+                            w.nearest = t;
+                            if (STATS) cn.tri_accept++;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (next_node) {
+        if (w.sp == 0) return true;
+        w.node = stack.pop(--w.sp);
+    }
+    if (!tri || next_node) walk_enter(w);
+    return false;
+}
+
 // walk_begin for the pooled kernel: same spheres + root visit, but the far child (if it has to be
 // visited) is returned in k2 instead of being pushed, because the walk may run on another lane.
 template <bool STATS>
@@ -654,53 +748,89 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 
 // ---- the pooled megakernel -----------------------------------------------------------------
 // Same per-ray arithmetic as trace_kernel, different division of labour.  In an outdoor scene only
-// about one ray in ten needs a real BVH walk, so a wave that walks its own rays steps ~10 live lanes
-// out of 64.  Here a workgroup of PT_POOL_WAVES waves pools its walks through LDS:
-//   * every lane OWNS one pixel of its wave's work item (path state, RNG, sums) and, separately, has
-//     a WALK SLOT that can carry any ray of the workgroup;
-//   * an owner whose new ray survives the root visit parks it in its LDS "box" and posts its thread
-//     id on its wave's ring (single producer); waves with free walk slots claim ring entries with a
-//     compare-and-swap on the ring head, load the ray from the owner's box and walk it; the closest
-//     hit goes back into the box and the owner shades it at its wave's next shading pass;
-//   * a wave starts walking only when enough rays are pending (or it has nothing else to do) and
-//     then keeps topping up, so the walks concentrate on few waves with well-filled lanes while the
-//     other waves only shade;
-//   * waves are persistent: when all 64 owners of a wave have finished their item the wave takes
-//     the next one from a global counter, and its walk slots keep serving the workgroup meanwhile.
-// LDS per workgroup: stacks [entry][thread] (24 KiB), boxes [field][thread] (12 KiB), rings.
-#define PT_POOL_WAVES 4
-#define PT_POOL_THREADS (64 * PT_POOL_WAVES)
-#define PT_POOL_STACK PT_LDS_STACK
-#ifndef PT_POOL_WAVES_PER_EU
-#define PT_POOL_WAVES_PER_EU 4  // 128 VGPRs: owner state and walk slot side by side
+// about one ray in ten needs a real BVH walk and those walks are long, so a wave that walks its own
+// rays steps ~10 live lanes out of 64, and a tile's pixels finish at very different times.  Here
+// neither paths nor pixels are tied to lanes:
+//   * a workgroup of PT_PP_WAVES persistent waves keeps PT_PP_PATHS path slots with their whole state
+//     in LDS, structure-of-arrays [field][slot]; a slot works on one JOB = one pixel of one work item
+//     (its frames in order, so the pixel's sums are the same sequential sums as in trace_kernel) and
+//     takes the next job when it is done: the group hands out the pixels of its open work item in
+//     order and opens the next item from the launch's item counter;
+//   * a slot id is always in exactly one place: one of the two READY rings (its ray has its closest
+//     hit: one ring for hits, one for misses and slots that have no ray yet), the PENDING ring (its
+//     ray survived the root visit and needs a walk), or in the hands of one lane;
+//   * a SHADING PASS pops up to 64 slots from one READY ring (so all its lanes run the same kind of
+//     code), shades them, sets up their next rays (spheres + the root's child pair) and pushes each
+//     slot to PENDING or back to a READY ring;
+//   * every lane also has a WALK SLOT in registers; a wave tops its free walk slots up from PENDING,
+//     steps all its walkers a few node visits per trip and pushes finished ones to READY;
+//   * pending rays go to the wave that already walks the most, so walks concentrate on few
+//     well-filled waves; a wave that found nothing to do for a while ignores such preferences, so
+//     they can never stall the group;
+//   * the running sums live in global memory (the item's partial-sum row, or the accumulation buffer
+//     itself in DIRECT mode) and are only touched by the lane that holds the slot.
+// Rings are multi-producer/multi-consumer: producers reserve positions with an atomic add on the
+// tail and then fill them; consumers claim positions with a compare-and-swap on the head and wait
+// for the entry to be filled (0 = not yet); a producer waits for the entry it is about to fill to be
+// empty.  Every wait is on a strictly older ring position, so waits cannot form a cycle.
+#define PT_PP_WAVES 4
+#define PT_PP_THREADS (64 * PT_PP_WAVES)
+#ifndef PT_PP_PATHS
+#define PT_PP_PATHS 320
 #endif
-enum : uint32_t { BOX_OX, BOX_OY, BOX_OZ, BOX_DX, BOX_DY, BOX_DZ, BOX_T, BOX_ID, BOX_U_NODE, BOX_V_NODE2, BOX_STATUS, BOX_STEPS, BOX_FIELDS };
-enum : uint32_t { BOX_EMPTY = 0, BOX_PENDING = 1, BOX_DONE = 2 };
+#define PT_PP_SEED (PT_PP_PATHS / PT_PP_WAVES)  // slots each wave gives their first job
+#ifndef PT_PP_QCAP
+#define PT_PP_QCAP 512   // ring capacity: a power of two >= PT_PP_PATHS
+#endif
+#ifndef PT_PP_STACK
+#define PT_PP_STACK 8    // traversal stack entries per walk slot kept in LDS; deeper ones spill
+#endif
+#define PT_PP_MAX_SPIN (1u << 20)
+#ifndef PT_PP_WAVES_PER_EU
+#define PT_PP_WAVES_PER_EU 4
+#endif
+static_assert(PT_PP_PATHS % PT_PP_WAVES == 0 && PT_PP_PATHS <= PT_PP_QCAP && (PT_PP_QCAP & (PT_PP_QCAP - 1)) == 0, "pool geometry");
 
-struct PoolShared {
-    uint32_t stack[PT_POOL_STACK][PT_POOL_THREADS];
-    uint32_t box[BOX_FIELDS][PT_POOL_THREADS];
-    uint32_t ring[PT_POOL_WAVES][64];
-    uint32_t tail[PT_POOL_WAVES];  // written by the producing wave only
-    uint32_t head[PT_POOL_WAVES];  // advanced by consumers (compare-and-swap)
-    uint32_t waves_done;
+enum : uint32_t {
+    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,  // the path's current ray
+    F_T, F_ID,                           // closest hit so far: t, index | is_tri << 30 | hit << 31
+    F_U, F_V,                            // barycentrics; while PENDING: node token to visit, far child (or none)
+    F_COLR, F_COLG, F_COLB, F_SEED, F_BOUNCE,
+    F_FRAME,                             // frame being rendered
+    F_FS,                                // have_ray | want_aov << 1 | sample << 2
+    F_XY, F_FEND, F_PIDX,                // the job: pixel x | y << 16, end frame, index of its float4 of sums
+    F_COST,                              // work estimate of the job so far
+    F_BASE
+};
+template <bool GIZMO, bool SPP1>
+struct PPFields {
+    static constexpr uint32_t RNG = F_BASE;                      // HybridTaus state (4) + sample sum (3), only when spp > 1
+    static constexpr uint32_t FSUM = F_BASE + 4u;
+    static constexpr uint32_t IDIR = F_BASE + (SPP1 ? 0u : 7u);  // first direction (3) + bounce limit, only with a gizmo sphere
+    static constexpr uint32_t LIMIT = IDIR + 3u;
+    static constexpr uint32_t COUNT = IDIR + (GIZMO ? 4u : 0u);
 };
 
-template <bool OVERFLOW>
-struct PoolStack {
-    uint32_t *lds;   // &sh.stack[0][tid]
-    uint32_t *spill;
-    size_t pitch;
-    __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
-    {
-        if (!OVERFLOW || sp < PT_POOL_STACK) lds[sp * PT_POOL_THREADS] = v;
-        else spill[(size_t)(sp - PT_POOL_STACK) * pitch] = v;
-    }
-    __device__ __forceinline__ uint32_t pop(uint32_t sp)
-    {
-        if (!OVERFLOW || sp < PT_POOL_STACK) return lds[sp * PT_POOL_THREADS];
-        return spill[(size_t)(sp - PT_POOL_STACK) * pitch];
-    }
+// Ring entries are slot id + 1 in 16 bits.
+typedef uint16_t pp_entry;
+__device__ __forceinline__ uint32_t ring_load(pp_entry *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ring_store(pp_entry *p, uint32_t v) { __hip_atomic_store(p, (pp_entry)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <uint32_t NF>
+struct PPShared {
+    uint32_t st[NF][PT_PP_PATHS];
+    uint32_t stack[PT_PP_STACK][PT_PP_THREADS];
+    pp_entry ready[PT_PP_QCAP];     // READY, ray missed everything (or no ray yet): sky, next path
+    pp_entry ready_hit[PT_PP_QCAP]; // READY, ray hit something: material, bounce
+    pp_entry pending[PT_PP_QCAP];
+    uint32_t ready_head, ready_tail, hit_head, hit_tail, pend_head, pend_tail;
+    uint32_t busy[PT_PP_WAVES];  // walkers per wave, published every trip
+    uint32_t live;               // slots that still have, or may still get, a job
+    // the group's open work item: its pixels are handed out in order to slots that need a job
+    uint32_t job_word;           // generation << 8 | pixels handed out (64 = all)
+    uint32_t job_lock;           // held by the lane that opens the next item
+    uint32_t no_more;            // the launch's item counter is exhausted
+    uint32_t it_x0, it_y0, it_fb, it_fend, it_index;
 };
 
 // Hand-shake words are accessed with relaxed workgroup-scope atomics (plain ds_read/ds_write that the
@@ -708,45 +838,192 @@ struct PoolStack {
 __device__ __forceinline__ uint32_t lds_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1, bool DIRECT>
-__global__ __launch_bounds__(PT_POOL_THREADS, PT_POOL_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
+struct PPStack {
+    uint32_t *lds;   // &sh.stack[0][tid]
+    uint32_t *spill;
+    size_t pitch;
+    __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
+    {
+        if (sp < PT_PP_STACK) lds[sp * PT_PP_THREADS] = v;
+        else spill[(size_t)(sp - PT_PP_STACK) * pitch] = v;
+    }
+    __device__ __forceinline__ uint32_t pop(uint32_t sp)
+    {
+        if (sp < PT_PP_STACK) return lds[sp * PT_PP_THREADS];
+        return spill[(size_t)(sp - PT_PP_STACK) * pitch];
+    }
+};
+
+// Wave-level push: every lane with `mine` appends `id`.  Called from wave-uniform code.
+__device__ __forceinline__ void ring_push(pp_entry *ring, uint32_t *tail, bool mine, uint32_t id, uint32_t lane, unsigned long long lt_mask)
 {
-    __shared__ PoolShared sh;
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u;
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the slot's state is written before its id shows up
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(tail, (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (mine) {
+        pp_entry *e = &ring[(base + (uint32_t)__popcll(m & lt_mask)) & (PT_PP_QCAP - 1u)];
+        // an older entry not yet taken out: never seen in practice; bounded so that a bug cannot hang the GPU
+        for (uint32_t spin = 0; ring_load(e) != 0u && spin < PT_PP_MAX_SPIN; spin++) __builtin_amdgcn_s_sleep(1);
+        ring_store(e, id + 1u);
+    }
+}
+
+// Wave-level pop: the lanes of `want` take up to popcount(want) ids; returns 0xFFFFFFFF for no id.
+__device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uint32_t *tail, unsigned long long want, uint32_t lane,
+                                            unsigned long long lt_mask)
+{
+    uint32_t h = 0, n = 0;
+    if (lane == 0) {
+        for (int attempt = 0; attempt < 4; attempt++) {
+            h = lds_load(head);
+            const uint32_t avail = lds_load(tail) - h;
+            if (avail == 0u || avail > PT_PP_QCAP) break;  // empty (or a torn pair of reads: try next trip)
+            const uint32_t m = min(avail, (uint32_t)__popcll(want));
+            if (atomicCAS(head, h, h + m) == h) { n = m; break; }
+        }
+    }
+    h = __builtin_amdgcn_readfirstlane(h);
+    n = __builtin_amdgcn_readfirstlane(n);
+    uint32_t id = 0xFFFFFFFFu;
+    if (n == 0u) return id;
+    const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+    if (((want >> lane) & 1ull) && rank < n) {
+        pp_entry *e = &ring[(h + rank) & (PT_PP_QCAP - 1u)];
+        // reserved by its producer, about to be filled (bounded like the wait above; a slot lost here
+        // stays "live", so the waves' idle limit ends the kernel and the error mark is set)
+        uint32_t v = ring_load(e);
+        for (uint32_t spin = 0; v == 0u && spin < PT_PP_MAX_SPIN; spin++) {
+            __builtin_amdgcn_s_sleep(1);
+            v = ring_load(e);
+        }
+        if (v != 0u) {
+            ring_store(e, 0u);
+            id = v - 1u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return id;
+}
+
+template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
+__global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
+{
+    using FL = PPFields<GIZMO, SPP1>;
+    __shared__ PPShared<FL::COUNT> sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const PtDeviceScene &sc = P.sc;
-    const bool primary = wv == ((blockIdx.x >> 3) & (PT_POOL_WAVES - 1u));
-    if (tid < PT_POOL_WAVES) { sh.tail[tid] = 0; sh.head[tid] = 0; }
-    if (tid == 0) sh.waves_done = 0;
-    sh.box[BOX_STATUS][tid] = BOX_EMPTY;
+    float4 *const sums = DIRECT ? P.accum : P.partial;
+    for (uint32_t i = tid; i < PT_PP_QCAP; i += PT_PP_THREADS) { sh.ready[i] = 0; sh.ready_hit[i] = 0; sh.pending[i] = 0; }
+    if (tid == 0) {
+        sh.ready_head = sh.ready_tail = sh.hit_head = sh.hit_tail = sh.pend_head = sh.pend_tail = 0;
+        for (uint32_t i = 0; i < PT_PP_WAVES; i++) sh.busy[i] = 0;
+        sh.live = PT_PP_PATHS;
+        sh.job_word = 64u;
+        sh.job_lock = 0;
+        sh.no_more = 0;
+    }
     __syncthreads();
 
-    PoolStack<OVERFLOW> stack{&sh.stack[0][tid], nullptr, 0};
-    if (OVERFLOW) {
-        stack.spill = P.gstack + ((size_t)blockIdx.x * PT_POOL_THREADS + tid);
-        stack.pitch = (size_t)gridDim.x * PT_POOL_THREADS;
-    }
+    PPStack stack{&sh.stack[0][tid], P.gstack ? P.gstack + ((size_t)blockIdx.x * PT_PP_THREADS + tid) : nullptr, (size_t)gridDim.x * PT_PP_THREADS};
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- owner side ----
-    enum : uint32_t { O_DONE = 0, O_READY = 1, O_WAIT = 2 };
-    uint32_t ostate = O_DONE;
-    bool have_item = false, out_of_items = false;
-    uint32_t item_index = 0, tile = 0, frame = 0, frame_end = 0, x = 0, y = 0;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t sample = 0, sx = 0, sy = 0, sz = 0, sw = 0;
-    v3 frame_sum = V3(0.0f, 0.0f, 0.0f), initial_d = V3(0.0f, 0.0f, 0.0f), color = V3(1.0f, 1.0f, 1.0f);
-    float seed = 0.0f;
-    uint32_t bounce = 0, limit = 0, cost = 0;
-    bool have_ray = false, want_aov = false, in_image = false;
-    uint32_t my_tail = 0;  // this wave's ring tail (only this wave writes it)
+    // Gives each lane with `need` a job for slot p, in lane order, from the group's open work item
+    // (opening the next one when its 64 pixels are handed out); false for the lanes left without a
+    // job because the launch has no items left.  Wave-uniform control flow.
+    auto assign_jobs = [&](bool need, uint32_t p) -> bool {
+        bool got = false;
+        for (;;) {
+            const unsigned long long nm = __ballot(need && !got);
+            if (nm == 0ull) break;
+            uint32_t first = 0, take = 0, x0 = 0, y0 = 0, fb = 0, fend = 0, index = 0;
+            if (lane == 0) {
+                for (uint32_t spin = 0; spin < PT_PP_MAX_SPIN; spin++) {
+                    const uint32_t jw = lds_load(&sh.job_word);  // generation << 8 | pixels handed out
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t done = jw & 0xFFu;
+                    if (done < 64u) {
+                        // read the item first, claim second: the claim fails if the item was replaced meanwhile
+                        x0 = lds_load(&sh.it_x0); y0 = lds_load(&sh.it_y0); fb = lds_load(&sh.it_fb); fend = lds_load(&sh.it_fend);
+                        index = lds_load(&sh.it_index);
+                        const uint32_t t = min((uint32_t)__popcll(nm), 64u - done);
+                        if (atomicCAS(&sh.job_word, jw, jw + t) == jw) { first = done; take = t; break; }
+                        continue;
+                    }
+                    if (lds_load(&sh.no_more) != 0u) break;
+                    if (atomicCAS(&sh.job_lock, 0u, 1u) != 0u) { __builtin_amdgcn_s_sleep(1); continue; }
+                    if (lds_load(&sh.job_word) == jw) {
+                        // still handed out completely, and nobody else is replacing it: open the next item
+                        uint32_t it = 0, tile = 0, f0 = 0, fc = 0;
+                        bool have = false;
+                        for (;;) {
+                            it = atomicAdd(P.next_item, 1u);
+                            if (it >= P.n_items) break;
+                            if (DIRECT) { tile = it; f0 = 0; fc = P.n_frames; }
+                            else { const uint4 rec = P.items[it]; tile = rec.x; f0 = rec.y; fc = rec.z; }
+                            if (fc != 0u) { have = true; break; }  // zero frames: an unused entry of the item table
+                        }
+                        if (!have) {
+                            lds_store(&sh.no_more, 1u);
+                        } else {
+                            const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+                            lds_store(&sh.it_x0, tbx * PT_TILE); lds_store(&sh.it_y0, tby * PT_TILE);
+                            lds_store(&sh.it_fb, f0); lds_store(&sh.it_fend, f0 + fc); lds_store(&sh.it_index, it);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            lds_store(&sh.job_word, ((jw >> 8) + 1u) << 8);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lds_store(&sh.job_lock, 0u);
+                }
+            }
+            take = __builtin_amdgcn_readfirstlane(take);
+            if (take == 0u) break;  // no items left
+            first = __builtin_amdgcn_readfirstlane(first);
+            x0 = __builtin_amdgcn_readfirstlane(x0); y0 = __builtin_amdgcn_readfirstlane(y0);
+            fb = __builtin_amdgcn_readfirstlane(fb); fend = __builtin_amdgcn_readfirstlane(fend);
+            index = __builtin_amdgcn_readfirstlane(index);
+            const uint32_t rank = (uint32_t)__popcll(nm & lt_mask);
+            if (need && !got && rank < take) {
+                const uint32_t pix = first + rank;
+                const uint32_t x = x0 + (pix & 7u), y = y0 + (pix >> 3);
+                const bool in_image = (x < P.cols) && (y < P.rows) && P.spp > 0;
+                const uint32_t pidx = DIRECT ? y * P.width + x : index * 64u + pix;
+                if (!DIRECT) sums[pidx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // also the rows of pixels outside the image
+                if (in_image) {
+                    sh.st[F_XY][p] = x | (y << 16);
+                    sh.st[F_FEND][p] = fend;
+                    sh.st[F_PIDX][p] = pidx;
+                    sh.st[F_COST][p] = 0u;
+                    sh.st[F_FRAME][p] = fb;
+                    sh.st[F_FS][p] = 0u;
+                    if (!SPP1) { sh.st[FL::FSUM][p] = 0u; sh.st[FL::FSUM + 1][p] = 0u; sh.st[FL::FSUM + 2][p] = 0u; }
+                    got = true;
+                }
+            }
+        }
+        return got;
+    };
+
+    // every wave gives its share of the slots their first job
+    for (uint32_t base = 0; base < PT_PP_SEED; base += 64u) {
+        const bool need = base + lane < PT_PP_SEED;
+        const uint32_t p = wv * PT_PP_SEED + base + lane;
+        const bool got = assign_jobs(need, p);
+        ring_push(sh.ready, &sh.ready_tail, got, p, lane, lt_mask);
+        const uint32_t n_dead = (uint32_t)__popcll(__ballot(need && !got));
+        if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
+    }
 
     // ---- walk slot ----
     bool wbusy = false;
-    uint32_t wowner = 0, wsteps = 0;
+    uint32_t wpath = 0, wsteps = 0;
     Ray wray;
     wray.o = wray.d = V3(0.0f, 0.0f, 0.0f);
-    Walk w;
+    WalkU w;
     w.rec.hit = w.rec.is_tri = false;
     w.rec.t = w.rec.u = w.rec.v = 0.0f;
     w.rec.index = 0;
@@ -754,105 +1031,175 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_POOL_WAVES_PER_EU) void pool_ke
     w.nearest = 9999.0f;
     w.node = 0;
     w.sp = 0;
+    w.leaf_next = w.leaf_left = 0;
 
-    // Every wave leaves the loop: normally when all waves of the group have run out of items, and
-    // in any case after max_idle consecutive trips without anything to do (a lost hand-shake would
-    // otherwise hang the GPU; the check after the loop reports it).
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_trips = 0, dg_idle = 0, dg_shades = 0, dg_ready = 0, dg_shade_cyc = 0, dg_steps = 0, dg_busy = 0, dg_walk_cyc = 0,
                        dg_claim_cyc = 0, dg_claims = 0, dg_s = 0;
 #endif
-    for (uint32_t idle = 0; idle < P.max_idle;) {
+    // Every wave leaves the loop: normally when no slot is live any more, and in any case after
+    // max_idle consecutive trips without anything to do (a lost hand-shake would otherwise hang the
+    // GPU; the check after the loop reports it).
+    uint32_t idle = 0;
+    while (idle < P.max_idle) {
         bool did_work = false;
+        const bool relaxed = idle >= 2u;      // nothing to do twice in a row: shade whatever is ready
+        const bool desperate = idle >= 32u;   // still nothing: walk whatever is pending
 #ifdef PT_DIAG
         dg_trips++;
 #endif
+        // wave-uniform view of the pool
+        uint32_t n_pend = lds_load(&sh.pend_tail) - lds_load(&sh.pend_head);
+        if (n_pend > PT_PP_QCAP) n_pend = 0;
+        uint32_t n_miss = lds_load(&sh.ready_tail) - lds_load(&sh.ready_head);
+        if (n_miss > PT_PP_QCAP) n_miss = 0;
+        uint32_t n_hit = lds_load(&sh.hit_tail) - lds_load(&sh.hit_head);
+        if (n_hit > PT_PP_QCAP) n_hit = 0;
+        const unsigned long long free_mask = __ballot(!wbusy);
+        const uint32_t n_free = (uint32_t)__popcll(free_mask);
 
-        // (a) item hand-over: all 64 owners finished -> write the sums out, take the next item
-        if (__ballot(ostate != O_DONE) == 0ull && !out_of_items) {
-            if (have_item) {
-                if (!DIRECT) P.partial[(size_t)item_index * 64u + lane] = acc;
-                else if (in_image) P.accum[(size_t)y * P.width + x] = acc;
-                const uint32_t c = wave_sum(cost);
-                if (P.cost && lane == 0) atomicAdd(&P.cost[tile], c);
-                have_item = false;
+#ifdef PT_DIAG
+        dg_s = clock64();
+#endif
+        // (a) top the walk slots up from PENDING.  Pending rays go to the wave that already has the
+        // most walkers and still has room (ties to the lower wave index), so that walks concentrate
+        // on few, well-filled waves; the others take rays only when so many wait that the leader
+        // cannot hold them.
+        bool leader = true;
+        for (uint32_t o = 0; o < PT_PP_WAVES; o++) {
+            const uint32_t ob = lds_load(&sh.busy[o]);
+            if (o != wv && ob < 64u && (ob > 64u - n_free || (ob == 64u - n_free && o < wv))) leader = false;
+        }
+        if (n_pend != 0u && n_free != 0u &&
+            (desperate || (leader ? (n_free >= P.pool_topup || n_pend >= n_free || n_free == 64u) : n_pend >= P.pool_start + 64u))) {
+            const uint32_t id = ring_pop(sh.pending, &sh.pend_head, &sh.pend_tail, free_mask, lane, lt_mask);
+            if (id != 0xFFFFFFFFu) {
+                const uint32_t p = id;
+                wpath = p;
+                wray.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
+                wray.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
+                const uint32_t hid = sh.st[F_ID][p];
+                w.rec.hit = (hid >> 31) != 0;
+                w.rec.is_tri = false;
+                w.rec.index = hid & 0x3FFFFFFFu;
+                w.rec.t = __uint_as_float(sh.st[F_T][p]);
+                w.rec.u = w.rec.v = 0.0f;
+                w.inv = V3(1.0f / wray.d.x, 1.0f / wray.d.y, 1.0f / wray.d.z);
+                w.nearest = 9999.0f;
+                w.node = sh.st[F_U][p];
+                w.sp = 0;
+                w.leaf_left = 0;
+                walk_enter(w);
+                const uint32_t k2 = sh.st[F_V][p];
+                if (k2 != 0xFFFFFFFFu) stack.push(w.sp++, k2);
+                wsteps = 0;
+                wbusy = true;
             }
-            uint32_t fb = 0, fc = 0;
-            for (;;) {
-                uint32_t it = 0;
-                if (lane == 0) it = atomicAdd(P.next_item, 1u);
-                it = __builtin_amdgcn_readfirstlane(it);
-                if (it >= P.n_items) { out_of_items = true; break; }
-                if (DIRECT) { tile = it; fb = 0; fc = P.n_frames; }
-                else { const uint4 rec = P.items[it]; tile = rec.x; fb = rec.y; fc = rec.z; }
-                if (fc != 0) { item_index = it; have_item = true; break; }
+            const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
+            if (gotm) did_work = true;
+#ifdef PT_DIAG
+            dg_claims += __popcll(gotm);
+#endif
+        }
+#ifdef PT_DIAG
+        dg_claim_cyc += clock64() - dg_s;
+        dg_s = clock64();
+#endif
+
+        // (b) step the walkers a few node visits; finished ones go back to READY
+        {
+            const uint32_t nb = (uint32_t)__popcll(__ballot(wbusy));
+            if (lane == 0) lds_store(&sh.busy[wv], nb);
+        }
+        if (__ballot(wbusy) != 0ull) {
+            did_work = true;
+            bool fin = false;
+            __builtin_amdgcn_s_setprio(3);  // a walk step is short and waits on memory: let it issue ahead of shading
+            for (uint32_t k = 0; k < P.pool_steps; k++) {
+#ifdef PT_DIAG
+                dg_steps++;
+                dg_busy += __popcll(__ballot(wbusy));
+#endif
+                if (wbusy) {
+                    wsteps++;
+                    if (walk_step_u<STATS>(sc, wray, w, stack, cn)) {
+                        const uint32_t p = wpath;
+                        sh.st[F_T][p] = __float_as_uint(w.rec.t);
+                        sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
+                        sh.st[F_U][p] = __float_as_uint(w.rec.u);
+                        sh.st[F_V][p] = __float_as_uint(w.rec.v);
+                        sh.st[F_COST][p] += wsteps;
+                        wbusy = false;
+                        fin = true;
+                    }
+                }
+                if (__ballot(wbusy) == 0ull) break;
             }
-            if (out_of_items) {
-                if (lane == 0) atomicAdd(&sh.waves_done, 1u);
-            } else {
-                const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
-                x = tbx * PT_TILE + (lane & 7u);
-                y = tby * PT_TILE + (lane >> 3);
-                in_image = (x < P.cols) && (y < P.rows) && P.spp > 0;
-                frame = fb;
-                frame_end = fb + fc;
-                sample = 0;
-                frame_sum = V3(0.0f, 0.0f, 0.0f);
-                cost = 0;
-                have_ray = false;
-                acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (DIRECT && in_image) acc = P.accum[(size_t)y * P.width + x];
-                ostate = in_image ? O_READY : O_DONE;
-                did_work = true;
+            __builtin_amdgcn_s_setprio(0);
+            ring_push(sh.ready, &sh.ready_tail, fin && !w.rec.hit, wpath, lane, lt_mask);
+            ring_push(sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, wpath, lane, lt_mask);
+            if (__ballot(fin)) {
+                n_miss = lds_load(&sh.ready_tail) - lds_load(&sh.ready_head);
+                if (n_miss > PT_PP_QCAP) n_miss = 0;
+                n_hit = lds_load(&sh.hit_tail) - lds_load(&sh.hit_head);
+                if (n_hit > PT_PP_QCAP) n_hit = 0;
             }
         }
-
-        // (b) owners whose walk came back
-        if (ostate == O_WAIT && lds_load(&sh.box[BOX_STATUS][tid]) == BOX_DONE) ostate = O_READY;
-
-        // wave-uniform view of the pool
-        uint32_t avail_total = 0;
-        for (uint32_t s2 = 0; s2 < PT_POOL_WAVES; s2++) avail_total += lds_load(&sh.tail[s2]) - lds_load(&sh.head[s2]);
-        const unsigned long long ready = __ballot(ostate == O_READY);
-        const uint32_t nready = (uint32_t)__popcll(ready);
-        const bool walking_any = __ballot(wbusy) != 0ull;
-
-        // (c) shading pass: worth it with enough ready owners, or when there is nothing else to do
-        if (nready >= P.refill_lanes || (nready > 0 && !walking_any && avail_total == 0)) {
-            did_work = true;
-            bool post = false;
 #ifdef PT_DIAG
-            dg_shades++;
-            dg_ready += nready;
+        dg_walk_cyc += clock64() - dg_s;
+#endif
+
+        // (c) shading pass over slots of one kind (hits, or misses and slots without a ray, so that the
+        // wave skips the code of the other kind): with a wave's worth of them (more for a wave busy
+        // walking), or when nothing else is left
+        const uint32_t n_busy = (uint32_t)__popcll(__ballot(wbusy));
+        const bool pass_hits = n_hit >= n_miss;
+        const uint32_t n_ready = pass_hits ? n_hit : n_miss;
+        if (n_ready != 0u && (relaxed || n_ready >= (n_busy >= P.pool_dense ? P.pool_shade_dense : P.refill_lanes) || (n_busy == 0u && n_pend == 0u))) {
+#ifdef PT_DIAG
             dg_s = clock64();
 #endif
-            if (ostate == O_READY) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t id = pass_hits ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
+                                          : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+            bool to_pending = false, to_ready = false, to_hit = false, finished = false;
+            const uint32_t p = id;
+            if (id != 0xFFFFFFFFu) {
+                const uint32_t xy = sh.st[F_XY][p], x = xy & 0xFFFFu, y = xy >> 16;
+                const uint32_t frame_end = sh.st[F_FEND][p], pidx = sh.st[F_PIDX][p];
+                float4 acc = sums[pidx];  // needed when a frame ends, which is most of the time: fetch it early
+                bool acc_dirty = false;
+                const uint32_t fs = sh.st[F_FS][p];
+                bool have_ray = (fs & 1u) != 0, want_aov = (fs & 2u) != 0;
+                uint32_t sample = fs >> 2;
+                uint32_t frame = sh.st[F_FRAME][p];
+                uint32_t bounce = 0, limit = P.depth;
+                v3 color = V3(1.0f, 1.0f, 1.0f), initial_d = V3(0.0f, 0.0f, 0.0f);
+                float seed = 0.0f;
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 Ray cur;
                 cur.o = cur.d = V3(0.0f, 0.0f, 0.0f);
                 if (have_ray) {
-                    cur.o = V3(__uint_as_float(sh.box[BOX_OX][tid]), __uint_as_float(sh.box[BOX_OY][tid]), __uint_as_float(sh.box[BOX_OZ][tid]));
-                    cur.d = V3(__uint_as_float(sh.box[BOX_DX][tid]), __uint_as_float(sh.box[BOX_DY][tid]), __uint_as_float(sh.box[BOX_DZ][tid]));
+                    cur.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
+                    cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
                     Closest c;
-                    const uint32_t id = sh.box[BOX_ID][tid];
-                    c.hit = (id >> 31) != 0;
-                    c.is_tri = ((id >> 30) & 1u) != 0;
-                    c.index = id & 0x3FFFFFFFu;
-                    c.t = __uint_as_float(sh.box[BOX_T][tid]);
-                    c.u = __uint_as_float(sh.box[BOX_U_NODE][tid]);
-                    c.v = __uint_as_float(sh.box[BOX_V_NODE2][tid]);
-                    cost += 4u + sh.box[BOX_STEPS][tid];
+                    const uint32_t hid = sh.st[F_ID][p];
+                    c.hit = (hid >> 31) != 0;
+                    c.is_tri = ((hid >> 30) & 1u) != 0;
+                    c.index = hid & 0x3FFFFFFFu;
+                    c.t = __uint_as_float(sh.st[F_T][p]);
+                    c.u = __uint_as_float(sh.st[F_U][p]);
+                    c.v = __uint_as_float(sh.st[F_V][p]);
+                    color = V3(__uint_as_float(sh.st[F_COLR][p]), __uint_as_float(sh.st[F_COLG][p]), __uint_as_float(sh.st[F_COLB][p]));
+                    seed = __uint_as_float(sh.st[F_SEED][p]);
+                    bounce = sh.st[F_BOUNCE][p];
+                    if (GIZMO) {
+                        initial_d = V3(__uint_as_float(sh.st[FL::IDIR][p]), __uint_as_float(sh.st[FL::IDIR + 1][p]), __uint_as_float(sh.st[FL::IDIR + 2][p]));
+                        limit = sh.st[FL::LIMIT][p];
+                    }
                     uint32_t prim;
-#ifdef PT_DEBUG_PIXEL
-                    if (x == 27 && y == 20) printf("P pre  b=%u o=%a %a %a d=%a %a %a hit=%d idx=%u t=%a seed=%a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)c.hit, c.index, c.t, seed);
-#endif
                     path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
-#ifdef PT_DEBUG_PIXEL
-                    if (x == 27 && y == 20) printf("P post b=%u o=%a %a %a d=%a %a %a done=%d col=%a %a %a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)path_done, color.x, color.y, color.z);
-#endif
                     if (want_aov) {
                         P.aov_prim[(size_t)y * P.width + x] = prim;
                         P.aov_t[(size_t)y * P.width + x] = c.hit ? c.t : 0.0f;
@@ -863,162 +1210,117 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_POOL_WAVES_PER_EU) void pool_ke
                 bool active = true;
                 while (active && (!have_ray || path_done || bounce >= limit)) {
                     if (have_ray) {
-                        const v3 path_color = path_done ? result : color;
+                        v3 path_color = path_done ? result : color;
                         path_done = false;
-                        if (!SPP1) { frame_sum = frame_sum + path_color; sample++; }
+                        if (!SPP1) {
+                            path_color = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p])) + path_color;
+                            sample++;
+                        }
                         if (SPP1 || sample == P.spp) {
-                            const v3 mean = (SPP1 ? path_color : frame_sum) * P.inv_spp;
+                            // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                            const v3 mean = path_color * P.inv_spp;
                             acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
-                            frame_sum = V3(0.0f, 0.0f, 0.0f);
+                            acc_dirty = true;
+                            path_color = V3(0.0f, 0.0f, 0.0f);
                             sample = 0;
                             frame++;
-                            if (frame == frame_end) { active = false; break; }
                         }
+                        if (!SPP1) {
+                            sh.st[FL::FSUM][p] = __float_as_uint(path_color.x);
+                            sh.st[FL::FSUM + 1][p] = __float_as_uint(path_color.y);
+                            sh.st[FL::FSUM + 2][p] = __float_as_uint(path_color.z);
+                        }
+                        if (frame == frame_end) { active = false; break; }
                     }
-                    if (sample == 0) {
+                    uint32_t sx, sy, sz, sw;
+                    if (SPP1 || sample == 0) {
                         const uint32_t time = P.time0 + frame * P.stride;  // compute.wgsl:85
                         sx = x; sy = y; sz = x + time; sw = y + time;
+                    } else {
+                        sx = sh.st[FL::RNG][p]; sy = sh.st[FL::RNG + 1][p]; sz = sh.st[FL::RNG + 2][p]; sw = sh.st[FL::RNG + 3][p];
                     }
                     const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
                     const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
                     const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
-                    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));
+                    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));  // compute.wgsl:109
                     cur.o = P.fr.origin;
                     cur.d = (ploc + smp) - P.fr.origin;
                     if (GIZMO) initial_d = cur.d;
                     color = V3(1.0f, 1.0f, 1.0f);
                     seed = pt_hybrid_taus(sx, sy, sz, sw);
+                    if (!SPP1) { sh.st[FL::RNG][p] = sx; sh.st[FL::RNG + 1][p] = sy; sh.st[FL::RNG + 2][p] = sz; sh.st[FL::RNG + 3][p] = sw; }
                     bounce = 0;
                     limit = P.depth;
                     have_ray = true;
                     want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
                 }
+                if (acc_dirty) sums[pidx] = acc;
+                const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
                 if (!active) {
-                    ostate = O_DONE;
+                    // the job is done
+                    if (P.cost) atomicAdd(&P.cost[(y / PT_TILE) * P.tiles_x + x / PT_TILE], cost);
+                    finished = true;
                 } else {
                     cn.rays++;
-                    // spheres + root visit; a surviving ray is parked in the box for a walk slot
+                    // spheres + root visit; a surviving ray goes to PENDING with its first node(s)
                     Walk nw;
                     uint32_t k2 = 0xFFFFFFFFu;
                     const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
-                    sh.box[BOX_OX][tid] = __float_as_uint(cur.o.x); sh.box[BOX_OY][tid] = __float_as_uint(cur.o.y); sh.box[BOX_OZ][tid] = __float_as_uint(cur.o.z);
-                    sh.box[BOX_DX][tid] = __float_as_uint(cur.d.x); sh.box[BOX_DY][tid] = __float_as_uint(cur.d.y); sh.box[BOX_DZ][tid] = __float_as_uint(cur.d.z);
-                    sh.box[BOX_T][tid] = __float_as_uint(nw.rec.t);
-                    sh.box[BOX_ID][tid] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
-                    sh.box[BOX_U_NODE][tid] = need_walk ? nw.node : 0u;
-                    sh.box[BOX_V_NODE2][tid] = need_walk ? k2 : 0u;
-                    sh.box[BOX_STEPS][tid] = 0u;
-                    lds_store(&sh.box[BOX_STATUS][tid], need_walk ? BOX_PENDING : BOX_DONE);
-                    ostate = need_walk ? O_WAIT : O_READY;
-                    post = need_walk;
+                    sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
+                    sh.st[F_DX][p] = __float_as_uint(cur.d.x); sh.st[F_DY][p] = __float_as_uint(cur.d.y); sh.st[F_DZ][p] = __float_as_uint(cur.d.z);
+                    sh.st[F_T][p] = __float_as_uint(nw.rec.t);
+                    sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
+                    sh.st[F_U][p] = need_walk ? nw.node : 0u;
+                    sh.st[F_V][p] = need_walk ? k2 : 0u;
+                    sh.st[F_COLR][p] = __float_as_uint(color.x); sh.st[F_COLG][p] = __float_as_uint(color.y); sh.st[F_COLB][p] = __float_as_uint(color.z);
+                    sh.st[F_SEED][p] = __float_as_uint(seed);
+                    sh.st[F_BOUNCE][p] = bounce;
+                    sh.st[F_FRAME][p] = frame;
+                    sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
+                    sh.st[F_COST][p] = cost;
+                    if (GIZMO) {
+                        sh.st[FL::IDIR][p] = __float_as_uint(initial_d.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(initial_d.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(initial_d.z);
+                        sh.st[FL::LIMIT][p] = limit;
+                    }
+                    to_pending = need_walk;
+                    to_ready = !need_walk && !nw.rec.hit;
+                    to_hit = !need_walk && nw.rec.hit;
                 }
             }
-            const unsigned long long posting = __ballot(post);
-            if (posting) {
-                if (post) sh.ring[wv][(my_tail + (uint32_t)__popcll(posting & lt_mask)) & 63u] = tid;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                my_tail += (uint32_t)__popcll(posting);
-                if (lane == 0) lds_store(&sh.tail[wv], my_tail);
-                avail_total += (uint32_t)__popcll(posting);
+            // slots whose job is done take the next one (or die when the launch has no items left)
+            if (__ballot(finished) != 0ull) {
+                const bool got = assign_jobs(finished, p);
+                to_ready = to_ready || (finished && got);
+                const uint32_t n_dead = (uint32_t)__popcll(__ballot(finished && !got));
+                if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
             }
+            ring_push(sh.pending, &sh.pend_tail, to_pending, p, lane, lt_mask);
+            ring_push(sh.ready, &sh.ready_tail, to_ready, p, lane, lt_mask);
+            ring_push(sh.ready_hit, &sh.hit_tail, to_hit, p, lane, lt_mask);
+            const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
+            if (gotm) did_work = true;
 #ifdef PT_DIAG
+            dg_shades++;
+            dg_ready += __popcll(gotm);
             dg_shade_cyc += clock64() - dg_s;
 #endif
         }
 
-        // (d) claim pending rays for free walk slots
-#ifdef PT_DIAG
-        dg_s = clock64();
-#endif
-        unsigned long long free_mask = __ballot(!wbusy);
-        // One wave of the group (rotating with the group index so that the walkers of a CU spread over
-        // its SIMDs) takes every pending ray it has room for; the others join in only when rays pile
-        // up or when none of their owners can be shaded.
-        if (free_mask && avail_total && (primary || avail_total >= P.pool_start || __ballot(ostate == O_READY) == 0ull)) {
-            for (uint32_t s2 = 0; s2 < PT_POOL_WAVES && free_mask; s2++) {
-                const uint32_t src = (wv + s2) & (PT_POOL_WAVES - 1u);
-                const uint32_t hd = lds_load(&sh.head[src]);
-                const uint32_t avail = lds_load(&sh.tail[src]) - hd;
-                if (avail == 0 || avail > 64u) continue;
-                const uint32_t n = min(avail, (uint32_t)__popcll(free_mask));
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // read the entries first, claim them second: if the claim succeeds the head had not
-                // moved, so the entries were unclaimed (and their owners parked) while they were read
-                const uint32_t rank = (uint32_t)__popcll(free_mask & lt_mask);
-                const uint32_t o = lds_load(&sh.ring[src][(hd + rank) & 63u]);
-                uint32_t ok = 0;
-                if (lane == 0) ok = atomicCAS(&sh.head[src], hd, hd + n) == hd ? 1u : 0u;
-                ok = __builtin_amdgcn_readfirstlane(ok);
-                if (!ok) continue;
-                if (!wbusy && rank < n) {
-                    wowner = o;
-                    wray.o = V3(__uint_as_float(sh.box[BOX_OX][o]), __uint_as_float(sh.box[BOX_OY][o]), __uint_as_float(sh.box[BOX_OZ][o]));
-                    wray.d = V3(__uint_as_float(sh.box[BOX_DX][o]), __uint_as_float(sh.box[BOX_DY][o]), __uint_as_float(sh.box[BOX_DZ][o]));
-                    const uint32_t id = sh.box[BOX_ID][o];
-                    w.rec.hit = (id >> 31) != 0;
-                    w.rec.is_tri = false;
-                    w.rec.index = id & 0x3FFFFFFFu;
-                    w.rec.t = __uint_as_float(sh.box[BOX_T][o]);
-                    w.rec.u = w.rec.v = 0.0f;
-                    w.inv = V3(1.0f / wray.d.x, 1.0f / wray.d.y, 1.0f / wray.d.z);
-                    w.nearest = 9999.0f;
-                    w.node = sh.box[BOX_U_NODE][o];
-                    w.sp = 0;
-                    const uint32_t k2 = sh.box[BOX_V_NODE2][o];
-                    if (k2 != 0xFFFFFFFFu) stack.push(w.sp++, k2);
-                    wsteps = 0;
-                    wbusy = true;
-                }
-                free_mask = __ballot(!wbusy);
-                did_work = true;
-#ifdef PT_DIAG
-                dg_claims += n;
-#endif
-            }
-        }
-#ifdef PT_DIAG
-        dg_claim_cyc += clock64() - dg_s;
-        dg_s = clock64();
-#endif
-
-        // (e) step the walkers a few node visits
-        for (uint32_t k = 0; k < P.pool_steps && __ballot(wbusy) != 0ull; k++) {
-            did_work = true;
-#ifdef PT_DIAG
-            dg_steps++;
-            dg_busy += __popcll(__ballot(wbusy));
-#endif
-            if (wbusy) {
-                wsteps++;
-                if (walk_step<STATS>(sc, wray, w, stack, cn)) {
-                    sh.box[BOX_T][wowner] = __float_as_uint(w.rec.t);
-                    sh.box[BOX_ID][wowner] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
-                    sh.box[BOX_U_NODE][wowner] = __float_as_uint(w.rec.u);
-                    sh.box[BOX_V_NODE2][wowner] = __float_as_uint(w.rec.v);
-                    sh.box[BOX_STEPS][wowner] = wsteps;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    lds_store(&sh.box[BOX_STATUS][wowner], BOX_DONE);
-                    wbusy = false;
-                }
-            }
-        }
-
-#ifdef PT_DIAG
-        dg_walk_cyc += clock64() - dg_s;
-        if (!did_work) dg_idle++;
-#endif
-        if (lds_load(&sh.waves_done) == PT_POOL_WAVES) break;
+        if (lds_load(&sh.live) == 0u) break;
         if (did_work) {
             idle = 0;
         } else {
             idle++;
+#ifdef PT_DIAG
+            dg_idle++;
+#endif
             __builtin_amdgcn_s_sleep(2);
         }
     }
 
 #ifdef PT_DIAG
     {
-        const uint32_t wid = blockIdx.x * PT_POOL_WAVES + wv;
+        const uint32_t wid = blockIdx.x * PT_PP_WAVES + wv;
         if (lane == 0 && wid < PT_DIAG_MAX_WAVES) {
             g_diag[8 * wid + 0] = diag_t0;
             g_diag[8 * wid + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1031,8 +1333,8 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_POOL_WAVES_PER_EU) void pool_ke
         }
     }
 #endif
-    // a wave that ran out of trips (should never happen) leaves a mark instead of hanging the GPU
-    if (__ballot(ostate != O_DONE || wbusy) != 0ull && lane == 0) atomicAdd(&P.counters[PT_NUM_COUNTERS - 1], 1ull << 48);
+    // a wave that gave up (should never happen) leaves a mark instead of hanging the GPU
+    if ((__ballot(wbusy) != 0ull || lds_load(&sh.live) != 0u) && lane == 0) atomicAdd(&P.counters[PT_NUM_COUNTERS - 1], 1ull << 48);
 
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 1;
@@ -1241,16 +1543,40 @@ static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool o
     return hipGetLastError();
 }
 
-// Pooled variant: a fixed grid of persistent workgroups that take items from *p.next_item.
-static hipError_t launch_pool(PtTraceParams p, uint32_t n_items, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
+// Pooled variant: a fixed grid of persistent workgroups that take items from *sch.next_item.
+uint32_t pt_pool_max_groups(uint32_t n_cus) { return n_cus * PT_PP_WAVES_PER_EU; }
+
+size_t pt_pool_gstack_bytes(uint32_t n_cus, uint32_t stack_depth)
+{
+    if (stack_depth <= PT_PP_STACK) return 0;
+    return (size_t)pt_pool_max_groups(n_cus) * PT_PP_THREADS * (stack_depth - PT_PP_STACK) * sizeof(uint32_t);
+}
+
+template <typename K>
+static uint32_t pool_groups_per_cu(K kernel)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, PT_PP_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
+    return (uint32_t)std::min(nb, PT_PP_WAVES_PER_EU);
+}
+
+static hipError_t launch_pool(PtTraceParams p, uint32_t n_items, uint32_t stack_depth, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(sch.next_item, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     p.next_item = sch.next_item;
     p.n_items = n_items;
-    const uint32_t groups = std::max(1u, std::min(sch.pool_groups, (n_items + PT_POOL_WAVES - 1u) / PT_POOL_WAVES));
-    const dim3 grid(groups, 1, 1), block(PT_POOL_THREADS, 1, 1);
-#define PT_LAUNCH(ST, GZ, S1, DI) hipLaunchKernelGGL((pool_kernel<ST, false, GZ, S1, DI>), grid, block, 0, stream, p)
+    p.gstack = stack_depth > PT_PP_STACK ? sch.pool_gstack : nullptr;
+    p.gstack_cap = stack_depth;
+    const dim3 block(PT_PP_THREADS, 1, 1);
+    const uint32_t want = (n_items + PT_PP_WAVES - 1u) / PT_PP_WAVES;
+#define PT_LAUNCH(ST, GZ, S1, DI)                                                                              \
+    do {                                                                                                       \
+        static const uint32_t per_cu = pool_groups_per_cu(pool_kernel<ST, GZ, S1, DI>);                        \
+        uint32_t groups = sch.pool_groups ? sch.pool_groups : per_cu * sch.n_cus;                              \
+        groups = std::max(1u, std::min(std::min(groups, want), pt_pool_max_groups(sch.n_cus)));                \
+        hipLaunchKernelGGL((pool_kernel<ST, GZ, S1, DI>), dim3(groups, 1, 1), block, 0, stream, p);            \
+    } while (0)
 #define PT_LAUNCH_DI(DI)                                                  \
     do {                                                                  \
         if (detailed_stats) PT_LAUNCH(true, true, false, DI);             \
@@ -1282,16 +1608,19 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     p.n_tiles = p.tiles_x * p.tiles_y;
     if (p.n_tiles == 0 || p.n_frames == 0) return hipSuccess;
     const bool overflow = spill_entries(stack_depth) > 0;
-    if (overflow && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
     p.cost = nullptr;
     // Few frames, no scheduling buffers, or a spilling stack (whose buffer has one column per tile
     // lane): one item per tile, frames added in order onto the stored sums.
-    const bool pool = sch.use_pool && sch.next_item && !overflow;
-    const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost || overflow;
+    // The pooled kernel has its own (shorter) LDS stack and spill buffer.
+    const bool pool = sch.use_pool && sch.next_item && sch.n_cus && (stack_depth <= PT_PP_STACK || sch.pool_gstack) && p.width <= 0xFFFFu &&
+                      p.height <= 0xFFFFu;  // the pooled kernel packs pixel coordinates into 16 bits each
+    const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost ||
+                        (overflow && !pool);
+    if (overflow && !pool && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
     if (direct) {
         p.items = nullptr;
         p.partial = nullptr;
-        if (pool) return launch_pool(p, p.n_tiles, detailed_stats, sch, stream);
+        if (pool) return launch_pool(p, p.n_tiles, stack_depth, detailed_stats, sch, stream);
         return launch_items(p, p.n_tiles, overflow, detailed_stats, stream);
     }
     hipError_t e;
@@ -1302,7 +1631,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
         first.partial = nullptr;
         first.n_frames = std::min(p.n_frames, sch.probe_frames);
         first.cost = sch.cost;
-        e = pool ? launch_pool(first, p.n_tiles, detailed_stats, sch, stream) : launch_items(first, p.n_tiles, overflow, detailed_stats, stream);
+        e = pool ? launch_pool(first, p.n_tiles, stack_depth, detailed_stats, sch, stream) : launch_items(first, p.n_tiles, overflow, detailed_stats, stream);
         if (e != hipSuccess) return e;
         *sch.cost_valid = true;
         p.time0 += first.n_frames * p.stride;
@@ -1318,7 +1647,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     p.items = sch.items;
     p.partial = sch.partial;
     p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
-    e = pool ? launch_pool(p, cap, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
+    e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
                        sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
