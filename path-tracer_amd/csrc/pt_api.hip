@@ -531,7 +531,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     if (const char *env = getenv("PTRT_POOL_DENSE")) p.pool_dense = (uint32_t)atoi(env);  // tuning aid
     p.pool_shade_dense = 128;
     if (const char *env = getenv("PTRT_POOL_SHADE_DENSE")) p.pool_shade_dense = (uint32_t)atoi(env);  // tuning aid
-    p.pool_steps = 4;
+    p.pool_steps = 8;
     if (const char *env = getenv("PTRT_POOL_STEPS")) p.pool_steps = (uint32_t)atoi(env);  // tuning aid
     p.max_idle = 1u << 22;
 

@@ -908,6 +908,25 @@ __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uin
     return id;
 }
 
+// The kernel's parameter block is large (scene pointers, camera frame, the root's child boxes).  Kept
+// in scalar registers for the whole persistent loop it overflows them, and every spilled value costs
+// vector instructions in the walk loop.  The shading pass and the job hand-out therefore re-read the
+// block from the kernel-argument segment (scalar loads, live only while they run); the asm statement
+// keeps the compiler from hoisting those loads back out of the loop.
+typedef const __attribute__((address_space(4))) uint32_t *PtKernargWords;
+static_assert(sizeof(PtTraceParams) % 4 == 0, "parameter block is read word by word");
+__device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
+{
+    PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();  // the block is the kernel's only argument
+    asm volatile("" : "+s"(kw));
+    uint32_t *lw = reinterpret_cast<uint32_t *>(&L);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
+}
+#define PT_FRESH_PARAMS(L) \
+    PtTraceParams L;       \
+    pt_fresh_params(L)
+
 template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
 {
@@ -916,7 +935,6 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const PtDeviceScene &sc = P.sc;
-    float4 *const sums = DIRECT ? P.accum : P.partial;
     for (uint32_t i = tid; i < PT_PP_QCAP; i += PT_PP_THREADS) { sh.ready[i] = 0; sh.ready_hit[i] = 0; sh.pending[i] = 0; }
     if (tid == 0) {
         sh.ready_head = sh.ready_tail = sh.hit_head = sh.hit_tail = sh.pend_head = sh.pend_tail = 0;
@@ -935,6 +953,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     // (opening the next one when its 64 pixels are handed out); false for the lanes left without a
     // job because the launch has no items left.  Wave-uniform control flow.
     auto assign_jobs = [&](bool need, uint32_t p) -> bool {
+        PT_FRESH_PARAMS(L);
+        float4 *const sums = DIRECT ? L.accum : L.partial;
         bool got = false;
         for (;;) {
             const unsigned long long nm = __ballot(need && !got);
@@ -960,16 +980,16 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         uint32_t it = 0, tile = 0, f0 = 0, fc = 0;
                         bool have = false;
                         for (;;) {
-                            it = atomicAdd(P.next_item, 1u);
-                            if (it >= P.n_items) break;
-                            if (DIRECT) { tile = it; f0 = 0; fc = P.n_frames; }
-                            else { const uint4 rec = P.items[it]; tile = rec.x; f0 = rec.y; fc = rec.z; }
+                            it = atomicAdd(L.next_item, 1u);
+                            if (it >= L.n_items) break;
+                            if (DIRECT) { tile = it; f0 = 0; fc = L.n_frames; }
+                            else { const uint4 rec = L.items[it]; tile = rec.x; f0 = rec.y; fc = rec.z; }
                             if (fc != 0u) { have = true; break; }  // zero frames: an unused entry of the item table
                         }
                         if (!have) {
                             lds_store(&sh.no_more, 1u);
                         } else {
-                            const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+                            const uint32_t tby = tile / L.tiles_x, tbx = tile - tby * L.tiles_x;
                             lds_store(&sh.it_x0, tbx * PT_TILE); lds_store(&sh.it_y0, tby * PT_TILE);
                             lds_store(&sh.it_fb, f0); lds_store(&sh.it_fend, f0 + fc); lds_store(&sh.it_index, it);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -990,8 +1010,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             if (need && !got && rank < take) {
                 const uint32_t pix = first + rank;
                 const uint32_t x = x0 + (pix & 7u), y = y0 + (pix >> 3);
-                const bool in_image = (x < P.cols) && (y < P.rows) && P.spp > 0;
-                const uint32_t pidx = DIRECT ? y * P.width + x : index * 64u + pix;
+                const bool in_image = (x < L.cols) && (y < L.rows) && L.spp > 0;
+                const uint32_t pidx = DIRECT ? y * L.width + x : index * 64u + pix;
                 if (!DIRECT) sums[pidx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // also the rows of pixels outside the image
                 if (in_image) {
                     sh.st[F_XY][p] = x | (y << 16);
@@ -1160,6 +1180,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
             dg_s = clock64();
 #endif
+            PT_FRESH_PARAMS(L);
+            const PtDeviceScene &sc = L.sc;
+            float4 *const sums = DIRECT ? L.accum : L.partial;
             const uint32_t id = pass_hits ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
                                           : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
             bool to_pending = false, to_ready = false, to_hit = false, finished = false;
@@ -1173,7 +1196,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 bool have_ray = (fs & 1u) != 0, want_aov = (fs & 2u) != 0;
                 uint32_t sample = fs >> 2;
                 uint32_t frame = sh.st[F_FRAME][p];
-                uint32_t bounce = 0, limit = P.depth;
+                uint32_t bounce = 0, limit = L.depth;
                 v3 color = V3(1.0f, 1.0f, 1.0f), initial_d = V3(0.0f, 0.0f, 0.0f);
                 float seed = 0.0f;
                 bool path_done = false;
@@ -1201,8 +1224,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     uint32_t prim;
                     path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
                     if (want_aov) {
-                        P.aov_prim[(size_t)y * P.width + x] = prim;
-                        P.aov_t[(size_t)y * P.width + x] = c.hit ? c.t : 0.0f;
+                        L.aov_prim[(size_t)y * L.width + x] = prim;
+                        L.aov_t[(size_t)y * L.width + x] = c.hit ? c.t : 0.0f;
                         want_aov = false;
                     }
                 }
@@ -1216,9 +1239,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             path_color = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p])) + path_color;
                             sample++;
                         }
-                        if (SPP1 || sample == P.spp) {
+                        if (SPP1 || sample == L.spp) {
                             // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
-                            const v3 mean = path_color * P.inv_spp;
+                            const v3 mean = path_color * L.inv_spp;
                             acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
                             acc_dirty = true;
                             path_color = V3(0.0f, 0.0f, 0.0f);
@@ -1234,31 +1257,31 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     }
                     uint32_t sx, sy, sz, sw;
                     if (SPP1 || sample == 0) {
-                        const uint32_t time = P.time0 + frame * P.stride;  // compute.wgsl:85
+                        const uint32_t time = L.time0 + frame * L.stride;  // compute.wgsl:85
                         sx = x; sy = y; sz = x + time; sw = y + time;
                     } else {
                         sx = sh.st[FL::RNG][p]; sy = sh.st[FL::RNG + 1][p]; sz = sh.st[FL::RNG + 2][p]; sw = sh.st[FL::RNG + 3][p];
                     }
                     const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
                     const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-                    const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
-                    const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));  // compute.wgsl:109
-                    cur.o = P.fr.origin;
-                    cur.d = (ploc + smp) - P.fr.origin;
+                    const v3 smp = v3_fma(py, L.fr.dv, L.fr.du * px);
+                    const v3 ploc = v3_fma((float)y, L.fr.dv, v3_fma((float)x, L.fr.du, L.fr.pixel00));  // compute.wgsl:109
+                    cur.o = L.fr.origin;
+                    cur.d = (ploc + smp) - L.fr.origin;
                     if (GIZMO) initial_d = cur.d;
                     color = V3(1.0f, 1.0f, 1.0f);
                     seed = pt_hybrid_taus(sx, sy, sz, sw);
                     if (!SPP1) { sh.st[FL::RNG][p] = sx; sh.st[FL::RNG + 1][p] = sy; sh.st[FL::RNG + 2][p] = sz; sh.st[FL::RNG + 3][p] = sw; }
                     bounce = 0;
-                    limit = P.depth;
+                    limit = L.depth;
                     have_ray = true;
-                    want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
+                    want_aov = (frame == 0 && sample == 0 && L.aov_prim != nullptr);
                 }
                 if (acc_dirty) sums[pidx] = acc;
                 const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
                 if (!active) {
                     // the job is done
-                    if (P.cost) atomicAdd(&P.cost[(y / PT_TILE) * P.tiles_x + x / PT_TILE], cost);
+                    if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
                     finished = true;
                 } else {
                     cn.rays++;
