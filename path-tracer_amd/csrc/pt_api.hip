@@ -330,7 +330,8 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
         h_nodes[2 * ((size_t)i + 1) + 1] = make_float4(n.max_corner[0], n.max_corner[1], n.max_corner[2], u2f(n.triangle_count));
         h_meta[i] = make_uint2(n.left_child_index, n.triangle_count);
     }
-    std::vector<float4> h_pos(3 * (size_t)n_idx), h_nrm(3 * (size_t)n_idx);
+    // one float4 of padding: the step-wise walk reads four float4 from a triangle's address
+    std::vector<float4> h_pos(3 * (size_t)n_idx + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);
     for (uint32_t k = 0; k < n_idx; k++) {
         const PtTriangle &t = tris[tri_idx[k]];
         // edges as the shader computes them (compute.wgsl:353-354)

@@ -262,9 +262,11 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         next_node = m.y == 0u;
     } else {
         const float4 *base = tri ? sc.tri_pos + 3 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
-        const float4 q0 = base[0], q1 = base[1], q2 = base[2];
-        float4 q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!tri) q3 = base[3];
+        // all four loads for every lane (the triangle array is padded by one float4): issued together
+        float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
+        // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
+        // interior-node branch, where they would cost that branch a second wait)
+        asm volatile("" : "+v"(q0.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z));
         if (!tri) {
             if (STATS) cn.interior++;
             float d1 = hit_aabb(o, w.inv, q0, q1);
@@ -287,30 +289,28 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             w.leaf_left--;
             next_node = w.leaf_left == 0u;
             if (STATS) cn.tri_tests++;
+            // Straight-line form of the shader's early-outs: the same values, all computed, then one
+            // test (a lane that would have left early only idles in a wave anyway).
             const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
             const v3 h = cross3(d, e2);
             const float a = dot3(e1, h);
-            if (!(a > -0.00001f && a < 0.00001f)) {
-                const float f = 1.0f / a;
-                const v3 s = o - f4_xyz(q0);
-                const float u = f * dot3(s, h);
-                if (!(u < 0.0f || u > 1.0f)) {
-                    const v3 q = cross3(s, e1);
-                    const float v = f * dot3(d, q);
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        const float t = f * dot3(e2, q);
-                        if (!(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t)) {
-                            w.rec.hit = true;
-                            w.rec.is_tri = true;
-                            w.rec.t = t;
-                            w.rec.index = slot;
-                            w.rec.u = u;
-                            w.rec.v = v;
-                            w.nearest = t;
-                            if (STATS) cn.tri_accept++;
-                        }
-                    }
-                }
+            const float f = 1.0f / a;
+            const v3 s = o - f4_xyz(q0);
+            const float u = f * dot3(s, h);
+            const v3 q = cross3(s, e1);
+            const float v = f * dot3(d, q);
+            const float t = f * dot3(e2, q);
+            const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                            !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
+            if (ok) {
+                w.rec.hit = true;
+                w.rec.is_tri = true;
+                w.rec.t = t;
+                w.rec.index = slot;
+                w.rec.u = u;
+                w.rec.v = v;
+                w.nearest = t;
+                if (STATS) cn.tri_accept++;
             }
         }
     }
@@ -849,8 +849,11 @@ struct PPStack {
     }
     __device__ __forceinline__ uint32_t pop(uint32_t sp)
     {
-        if (sp < PT_PP_STACK) return lds[sp * PT_PP_THREADS];
-        return spill[(size_t)(sp - PT_PP_STACK) * pitch];
+        // the LDS read always (clamped), the spill read as a rare branch: keeps the common case a plain ds_read
+        uint32_t v = lds[min(sp, (uint32_t)PT_PP_STACK - 1u) * PT_PP_THREADS];
+        asm volatile("" : "+v"(v));  // keeps the two reads from being merged into one generic-address load
+        if (sp >= PT_PP_STACK) v = spill[(size_t)(sp - PT_PP_STACK) * pitch];
+        return v;
     }
 };
 
