@@ -15,6 +15,8 @@
 // sample/frame immediately, so a wave only idles when every lane has run out of frames.
 #include "pt_kernels.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -773,7 +775,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 // tail and then fill them; consumers claim positions with a compare-and-swap on the head and wait
 // for the entry to be filled (0 = not yet); a producer waits for the entry it is about to fill to be
 // empty.  Every wait is on a strictly older ring position, so waits cannot form a cycle.
+#ifndef PT_PP_WAVES
 #define PT_PP_WAVES 4
+#endif
 #define PT_PP_THREADS (64 * PT_PP_WAVES)
 #ifndef PT_PP_PATHS
 #define PT_PP_PATHS 320
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_trips = 0, dg_idle = 0, dg_shades = 0, dg_ready = 0, dg_shade_cyc = 0, dg_steps = 0, dg_busy = 0, dg_walk_cyc = 0,
-                       dg_claim_cyc = 0, dg_claims = 0, dg_s = 0;
+                       dg_claim_cyc = 0, dg_claims = 0, dg_s = 0, dg_hit_passes = 0, dg_hit_lanes = 0, dg_hit_cyc = 0;
 #endif
     // Every wave leaves the loop: normally when no slot is live any more, and in any case after
     // max_idle consecutive trips without anything to do (a lost hand-shake would otherwise hang the
@@ -1186,107 +1190,113 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             PT_FRESH_PARAMS(L);
             const PtDeviceScene &sc = L.sc;
             float4 *const sums = DIRECT ? L.accum : L.partial;
-            const uint32_t id = pass_hits ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
-                                          : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
             bool to_pending = false, to_ready = false, to_hit = false, finished = false;
-            const uint32_t p = id;
-            if (id != 0xFFFFFFFFu) {
+            uint32_t p = 0xFFFFFFFFu;
+            // One body, compiled twice: in a pass over hits every lane has a ray that hit something, in a
+            // pass over misses no lane does, so each copy drops the other kind's code.  The order inside is
+            // chosen for memory latency: the loads whose values are needed last (the pixel's sums, the sky
+            // texel of a miss) are issued first, and the next ray is set up before their values are used.
+            auto shading_pass = [&](auto hits_tag) {
+                constexpr bool HITS = decltype(hits_tag)::value;
+                p = HITS ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
+                         : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+                if (p == 0xFFFFFFFFu) return;
                 const uint32_t xy = sh.st[F_XY][p], x = xy & 0xFFFFu, y = xy >> 16;
                 const uint32_t frame_end = sh.st[F_FEND][p], pidx = sh.st[F_PIDX][p];
-                float4 acc = sums[pidx];  // needed when a frame ends, which is most of the time: fetch it early
-                bool acc_dirty = false;
+                float4 acc = sums[pidx];
                 const uint32_t fs = sh.st[F_FS][p];
-                bool have_ray = (fs & 1u) != 0, want_aov = (fs & 2u) != 0;
+                const bool had_ray = HITS || (fs & 1u) != 0;
+                bool want_aov = (fs & 2u) != 0;
                 uint32_t sample = fs >> 2;
                 uint32_t frame = sh.st[F_FRAME][p];
                 uint32_t bounce = 0, limit = L.depth;
                 v3 color = V3(1.0f, 1.0f, 1.0f), initial_d = V3(0.0f, 0.0f, 0.0f);
                 float seed = 0.0f;
-                bool path_done = false;
-                v3 result = V3(0.0f, 0.0f, 0.0f);
                 Ray cur;
                 cur.o = cur.d = V3(0.0f, 0.0f, 0.0f);
-                if (have_ray) {
-                    cur.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
+                bool retire = false;                     // the path ends in this pass
+                v3 path_color = V3(0.0f, 0.0f, 0.0f);    // its colour (a miss: still to be multiplied by the sky texel)
+                v3 sky = V3(1.0f, 1.0f, 1.0f);
+                if (had_ray) {
                     cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
-                    Closest c;
-                    const uint32_t hid = sh.st[F_ID][p];
-                    c.hit = (hid >> 31) != 0;
-                    c.is_tri = ((hid >> 30) & 1u) != 0;
-                    c.index = hid & 0x3FFFFFFFu;
-                    c.t = __uint_as_float(sh.st[F_T][p]);
-                    c.u = __uint_as_float(sh.st[F_U][p]);
-                    c.v = __uint_as_float(sh.st[F_V][p]);
                     color = V3(__uint_as_float(sh.st[F_COLR][p]), __uint_as_float(sh.st[F_COLG][p]), __uint_as_float(sh.st[F_COLB][p]));
-                    seed = __uint_as_float(sh.st[F_SEED][p]);
-                    bounce = sh.st[F_BOUNCE][p];
-                    if (GIZMO) {
-                        initial_d = V3(__uint_as_float(sh.st[FL::IDIR][p]), __uint_as_float(sh.st[FL::IDIR + 1][p]), __uint_as_float(sh.st[FL::IDIR + 2][p]));
-                        limit = sh.st[FL::LIMIT][p];
-                    }
-                    uint32_t prim;
-                    path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
-                    if (want_aov) {
-                        L.aov_prim[(size_t)y * L.width + x] = prim;
-                        L.aov_t[(size_t)y * L.width + x] = c.hit ? c.t : 0.0f;
-                        want_aov = false;
+                    if constexpr (!HITS) {
+                        // compute.wgsl:140-143
+                        if (STATS) cn.sky++;
+                        sky = sky_lookup(sc, cur.d);
+                        path_color = color;
+                        retire = true;
+                        if (want_aov) {
+                            L.aov_prim[(size_t)y * L.width + x] = 0xFFFFFFFFu;
+                            L.aov_t[(size_t)y * L.width + x] = 0.0f;
+                            want_aov = false;
+                        }
+                    } else {
+                        cur.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
+                        Closest c;
+                        const uint32_t hid = sh.st[F_ID][p];
+                        c.hit = true;
+                        c.is_tri = ((hid >> 30) & 1u) != 0;
+                        c.index = hid & 0x3FFFFFFFu;
+                        c.t = __uint_as_float(sh.st[F_T][p]);
+                        c.u = __uint_as_float(sh.st[F_U][p]);
+                        c.v = __uint_as_float(sh.st[F_V][p]);
+                        seed = __uint_as_float(sh.st[F_SEED][p]);
+                        bounce = sh.st[F_BOUNCE][p];
+                        if constexpr (GIZMO) {
+                            initial_d = V3(__uint_as_float(sh.st[FL::IDIR][p]), __uint_as_float(sh.st[FL::IDIR + 1][p]), __uint_as_float(sh.st[FL::IDIR + 2][p]));
+                            limit = sh.st[FL::LIMIT][p];
+                        }
+                        uint32_t prim;
+                        v3 result = V3(0.0f, 0.0f, 0.0f);
+                        const bool path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
+                        if (want_aov) {
+                            L.aov_prim[(size_t)y * L.width + x] = prim;
+                            L.aov_t[(size_t)y * L.width + x] = c.t;
+                            want_aov = false;
+                        }
+                        // rayColor returns: the path's colour, or the throughput when the bounces run out (compute.wgsl:121)
+                        retire = path_done || bounce >= limit;
+                        path_color = path_done ? result : color;
                     }
                 }
-                // retire finished paths, start new ones (compute.wgsl:112-128)
-                bool active = true;
-                while (active && (!have_ray || path_done || bounce >= limit)) {
-                    if (have_ray) {
-                        v3 path_color = path_done ? result : color;
-                        path_done = false;
-                        if (!SPP1) {
-                            path_color = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p])) + path_color;
-                            sample++;
-                        }
-                        if (SPP1 || sample == L.spp) {
-                            // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
-                            const v3 mean = path_color * L.inv_spp;
-                            acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
-                            acc_dirty = true;
-                            path_color = V3(0.0f, 0.0f, 0.0f);
-                            sample = 0;
-                            frame++;
-                        }
-                        if (!SPP1) {
-                            sh.st[FL::FSUM][p] = __float_as_uint(path_color.x);
-                            sh.st[FL::FSUM + 1][p] = __float_as_uint(path_color.y);
-                            sh.st[FL::FSUM + 2][p] = __float_as_uint(path_color.z);
-                        }
-                        if (frame == frame_end) { active = false; break; }
+                // frame and sample counters of the retiring path (compute.wgsl:112-128); its colour is added below
+                bool frame_ends = false;
+                if (retire) {
+                    if constexpr (!SPP1) sample++;
+                    if (SPP1 || sample == L.spp) {
+                        frame_ends = true;
+                        sample = 0;
+                        frame++;
                     }
-                    uint32_t sx, sy, sz, sw;
-                    if (SPP1 || sample == 0) {
+                    finished = frame == frame_end;
+                }
+                const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
+                if (finished) {
+                    if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                } else {
+                    if (!had_ray || retire) {
+                        // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
+                        uint32_t sx, sy, sz, sw;
                         const uint32_t time = L.time0 + frame * L.stride;  // compute.wgsl:85
                         sx = x; sy = y; sz = x + time; sw = y + time;
-                    } else {
-                        sx = sh.st[FL::RNG][p]; sy = sh.st[FL::RNG + 1][p]; sz = sh.st[FL::RNG + 2][p]; sw = sh.st[FL::RNG + 3][p];
+                        if constexpr (!SPP1) {
+                            if (sample != 0) { sx = sh.st[FL::RNG][p]; sy = sh.st[FL::RNG + 1][p]; sz = sh.st[FL::RNG + 2][p]; sw = sh.st[FL::RNG + 3][p]; }
+                        }
+                        const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                        const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                        const v3 smp = v3_fma(py, L.fr.dv, L.fr.du * px);
+                        const v3 ploc = v3_fma((float)y, L.fr.dv, v3_fma((float)x, L.fr.du, L.fr.pixel00));  // compute.wgsl:109
+                        cur.o = L.fr.origin;
+                        cur.d = (ploc + smp) - L.fr.origin;
+                        if constexpr (GIZMO) initial_d = cur.d;
+                        color = V3(1.0f, 1.0f, 1.0f);
+                        seed = pt_hybrid_taus(sx, sy, sz, sw);
+                        if constexpr (!SPP1) { sh.st[FL::RNG][p] = sx; sh.st[FL::RNG + 1][p] = sy; sh.st[FL::RNG + 2][p] = sz; sh.st[FL::RNG + 3][p] = sw; }
+                        bounce = 0;
+                        limit = L.depth;
+                        want_aov = (frame == 0 && sample == 0 && L.aov_prim != nullptr);
                     }
-                    const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-                    const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-                    const v3 smp = v3_fma(py, L.fr.dv, L.fr.du * px);
-                    const v3 ploc = v3_fma((float)y, L.fr.dv, v3_fma((float)x, L.fr.du, L.fr.pixel00));  // compute.wgsl:109
-                    cur.o = L.fr.origin;
-                    cur.d = (ploc + smp) - L.fr.origin;
-                    if (GIZMO) initial_d = cur.d;
-                    color = V3(1.0f, 1.0f, 1.0f);
-                    seed = pt_hybrid_taus(sx, sy, sz, sw);
-                    if (!SPP1) { sh.st[FL::RNG][p] = sx; sh.st[FL::RNG + 1][p] = sy; sh.st[FL::RNG + 2][p] = sz; sh.st[FL::RNG + 3][p] = sw; }
-                    bounce = 0;
-                    limit = L.depth;
-                    have_ray = true;
-                    want_aov = (frame == 0 && sample == 0 && L.aov_prim != nullptr);
-                }
-                if (acc_dirty) sums[pidx] = acc;
-                const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
-                if (!active) {
-                    // the job is done
-                    if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
-                    finished = true;
-                } else {
                     cn.rays++;
                     // spheres + root visit; a surviving ray goes to PENDING with its first node(s)
                     Walk nw;
@@ -1304,7 +1314,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     sh.st[F_FRAME][p] = frame;
                     sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
                     sh.st[F_COST][p] = cost;
-                    if (GIZMO) {
+                    if constexpr (GIZMO) {
                         sh.st[FL::IDIR][p] = __float_as_uint(initial_d.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(initial_d.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(initial_d.z);
                         sh.st[FL::LIMIT][p] = limit;
                     }
@@ -1312,7 +1322,28 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     to_ready = !need_walk && !nw.rec.hit;
                     to_hit = !need_walk && nw.rec.hit;
                 }
-            }
+                // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
+                if (retire) {
+                    if constexpr (!HITS) path_color = path_color * sky;
+                    if constexpr (!SPP1)
+                        path_color = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p])) + path_color;
+                    if (frame_ends) {
+                        // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                        const v3 mean = path_color * L.inv_spp;
+                        acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                        sums[pidx] = acc;
+                        path_color = V3(0.0f, 0.0f, 0.0f);
+                    }
+                    if constexpr (!SPP1) {
+                        sh.st[FL::FSUM][p] = __float_as_uint(path_color.x);
+                        sh.st[FL::FSUM + 1][p] = __float_as_uint(path_color.y);
+                        sh.st[FL::FSUM + 2][p] = __float_as_uint(path_color.z);
+                    }
+                }
+            };
+            if (pass_hits) shading_pass(std::true_type{});
+            else shading_pass(std::false_type{});
+            const uint32_t id = p;
             // slots whose job is done take the next one (or die when the launch has no items left)
             if (__ballot(finished) != 0ull) {
                 const bool got = assign_jobs(finished, p);
@@ -1329,6 +1360,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             dg_shades++;
             dg_ready += __popcll(gotm);
             dg_shade_cyc += clock64() - dg_s;
+            if (pass_hits) { dg_hit_passes++; dg_hit_lanes += __popcll(gotm); dg_hit_cyc += clock64() - dg_s; }
 #endif
         }
 
@@ -1351,6 +1383,12 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             g_diag[8 * wid + 0] = diag_t0;
             g_diag[8 * wid + 1] = __builtin_amdgcn_s_memrealtime();
             g_diag[8 * wid + 2] = dg_trips | (dg_idle << 32);
+            g_diag_marks[(wid & 63u) * 8 + 0] = dg_hit_passes;  // a sample of 64 waves is enough for these
+            g_diag_marks[(wid & 63u) * 8 + 1] = dg_hit_lanes;
+            g_diag_marks[(wid & 63u) * 8 + 2] = dg_hit_cyc;
+            g_diag_marks[(wid & 63u) * 8 + 3] = dg_shades;
+            g_diag_marks[(wid & 63u) * 8 + 4] = dg_ready;
+            g_diag_marks[(wid & 63u) * 8 + 5] = dg_shade_cyc;
             g_diag[8 * wid + 3] = dg_shades | (dg_ready << 32);
             g_diag[8 * wid + 4] = dg_shade_cyc;
             g_diag[8 * wid + 5] = dg_steps | (dg_busy << 32);
@@ -1570,7 +1608,7 @@ static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool o
 }
 
 // Pooled variant: a fixed grid of persistent workgroups that take items from *sch.next_item.
-uint32_t pt_pool_max_groups(uint32_t n_cus) { return n_cus * PT_PP_WAVES_PER_EU; }
+uint32_t pt_pool_max_groups(uint32_t n_cus) { return n_cus * std::max(1, 4 * PT_PP_WAVES_PER_EU / PT_PP_WAVES); }
 
 size_t pt_pool_gstack_bytes(uint32_t n_cus, uint32_t stack_depth)
 {
@@ -1583,7 +1621,7 @@ static uint32_t pool_groups_per_cu(K kernel)
 {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, PT_PP_THREADS, 0) != hipSuccess || nb < 1) nb = 1;
-    return (uint32_t)std::min(nb, PT_PP_WAVES_PER_EU);
+    return (uint32_t)std::min(nb, std::max(1, 4 * PT_PP_WAVES_PER_EU / PT_PP_WAVES));
 }
 
 static hipError_t launch_pool(PtTraceParams p, uint32_t n_items, uint32_t stack_depth, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
@@ -1639,7 +1677,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     // lane): one item per tile, frames added in order onto the stored sums.
     // The pooled kernel has its own (shorter) LDS stack and spill buffer.
     const bool pool = sch.use_pool && sch.next_item && sch.n_cus && (stack_depth <= PT_PP_STACK || sch.pool_gstack) && p.width <= 0xFFFFu &&
-                      p.height <= 0xFFFFu;  // the pooled kernel packs pixel coordinates into 16 bits each
+                      p.height <= 0xFFFFu && p.depth >= 1u;  // it packs pixel coordinates into 16 bits each and gives every new path a ray
     const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost ||
                         (overflow && !pool);
     if (overflow && !pool && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;

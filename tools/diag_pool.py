@@ -48,3 +48,12 @@ ws = steps.reshape(-1, 4) if len(steps) % 4 == 0 else None
 if ws is not None:
     srt = np.sort(ws, axis=1)[:, ::-1]
     print("walk steps by rank within the group (most-walking wave first): " + " ".join(f"{v:.0f}" for v in srt.mean(axis=0)))
+
+marks = np.zeros((64, 8), np.uint64)
+L.pt_diag_read_marks.argtypes = [C.c_void_p, C.c_size_t]
+L.pt_diag_read_marks(marks.ctypes.data_as(C.c_void_p), marks.nbytes)
+m = marks.astype(np.float64).sum(axis=0)
+if m[3] > 0:
+    hp, hl, hc, ap, al, ac = m[:6]
+    print("hit passes %.1f%% of passes: %.1f lanes, %.0f cycles; miss passes: %.1f lanes, %.0f cycles" % (
+        100 * hp / ap, hl / max(hp, 1), hc / max(hp, 1), (al - hl) / max(ap - hp, 1), (ac - hc) / max(ap - hp, 1)))
