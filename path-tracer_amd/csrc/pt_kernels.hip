@@ -512,7 +512,7 @@ __device__ __forceinline__ bool shade_ray(const PtDeviceScene &sc, Ray &cur, con
 // Diagnostic build only (make diag): per-wave start/end stamps, hardware id and loop trip count.
 #define PT_DIAG_MAX_WAVES (1u << 18)
 __device__ unsigned long long g_diag[8 * PT_DIAG_MAX_WAVES];
-__device__ unsigned long long g_diag_marks[8 * 64];  // first 64 work items: realtime at every 1024th loop trip
+__device__ unsigned long long g_diag_marks[3 * 8 * 64];  // first 64 work items: realtime at every 1024th loop trip
 #endif
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -878,6 +878,30 @@ __device__ __forceinline__ void ring_push(pp_entry *ring, uint32_t *tail, bool m
     }
 }
 
+// Three pushes at once (a lane appends to at most one of the rings): one fence, and the three tail
+// reservations made by three lanes in the same instruction instead of one after the other.
+__device__ __forceinline__ void ring_push3(pp_entry *r0, uint32_t *t0, bool m0, pp_entry *r1, uint32_t *t1, bool m1, pp_entry *r2, uint32_t *t2,
+                                           bool m2, uint32_t id, uint32_t lane, unsigned long long lt_mask)
+{
+    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2);
+    if ((b0 | b1 | b2) == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the slots' state is written before their ids show up
+    uint32_t base = 0;
+    {
+        const uint32_t n = lane == 0 ? (uint32_t)__popcll(b0) : lane == 1 ? (uint32_t)__popcll(b1) : (uint32_t)__popcll(b2);
+        uint32_t *t = lane == 0 ? t0 : lane == 1 ? t1 : t2;
+        if (lane < 3u && n != 0u) base = atomicAdd(t, n);
+    }
+    const uint32_t base0 = __shfl(base, 0, 64), base1 = __shfl(base, 1, 64), base2 = __shfl(base, 2, 64);
+    if (m0 || m1 || m2) {
+        pp_entry *ring = m0 ? r0 : m1 ? r1 : r2;
+        const uint32_t pos = m0 ? base0 + (uint32_t)__popcll(b0 & lt_mask) : m1 ? base1 + (uint32_t)__popcll(b1 & lt_mask) : base2 + (uint32_t)__popcll(b2 & lt_mask);
+        pp_entry *e = &ring[pos & (PT_PP_QCAP - 1u)];
+        for (uint32_t spin = 0; ring_load(e) != 0u && spin < PT_PP_MAX_SPIN; spin++) __builtin_amdgcn_s_sleep(1);
+        ring_store(e, id + 1u);
+    }
+}
+
 // Wave-level pop: the lanes of `want` take up to popcount(want) ids; returns 0xFFFFFFFF for no id.
 __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uint32_t *tail, unsigned long long want, uint32_t lane,
                                             unsigned long long lt_mask)
@@ -930,9 +954,16 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
 }
-#define PT_FRESH_PARAMS(L) \
-    PtTraceParams L;       \
-    pt_fresh_params(L)
+// The pointers are taken from the kernel argument itself: the compiler knows that those point to
+// global memory, while a pointer rebuilt from plain words would be dereferenced through the slower
+// generic-address path.
+#define PT_FRESH_PARAMS(L)                                                                                       \
+    PtTraceParams L;                                                                                             \
+    pt_fresh_params(L);                                                                                          \
+    L.sc.spheres = P.sc.spheres; L.sc.nodes = P.sc.nodes; L.sc.node_meta = P.sc.node_meta;                      \
+    L.sc.tri_pos = P.sc.tri_pos; L.sc.tri_nrm = P.sc.tri_nrm; L.sc.sky = P.sc.sky;                              \
+    L.items = P.items; L.partial = P.partial; L.cost = P.cost; L.accum = P.accum;                               \
+    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t; L.next_item = P.next_item
 
 template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
@@ -1027,7 +1058,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     sh.st[F_COST][p] = 0u;
                     sh.st[F_FRAME][p] = fb;
                     sh.st[F_FS][p] = 0u;
-                    if (!SPP1) { sh.st[FL::FSUM][p] = 0u; sh.st[FL::FSUM + 1][p] = 0u; sh.st[FL::FSUM + 2][p] = 0u; }
+                    if constexpr (!SPP1) { sh.st[FL::FSUM][p] = 0u; sh.st[FL::FSUM + 1][p] = 0u; sh.st[FL::FSUM + 2][p] = 0u; }
                     got = true;
                 }
             }
@@ -1063,7 +1094,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_trips = 0, dg_idle = 0, dg_shades = 0, dg_ready = 0, dg_shade_cyc = 0, dg_steps = 0, dg_busy = 0, dg_walk_cyc = 0,
-                       dg_claim_cyc = 0, dg_claims = 0, dg_s = 0, dg_hit_passes = 0, dg_hit_lanes = 0, dg_hit_cyc = 0;
+                       dg_claim_cyc = 0, dg_claims = 0, dg_s = 0, dg_hit_passes = 0, dg_hit_lanes = 0, dg_hit_cyc = 0, dg_s2 = 0;
+    unsigned long long dg_sec[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg_hist[5] = {0, 0, 0, 0, 0};
 #endif
     // Every wave leaves the loop: normally when no slot is live any more, and in any case after
     // max_idle consecutive trips without anything to do (a lost hand-shake would otherwise hang the
@@ -1147,6 +1180,10 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
                 dg_steps++;
                 dg_busy += __popcll(__ballot(wbusy));
+                {
+                    const uint32_t nb = (uint32_t)__popcll(__ballot(wbusy));
+                    dg_hist[nb <= 8 ? 0 : nb <= 16 ? 1 : nb <= 32 ? 2 : nb <= 48 ? 3 : 4]++;
+                }
 #endif
                 if (wbusy) {
                     wsteps++;
@@ -1164,8 +1201,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 if (__ballot(wbusy) == 0ull) break;
             }
             __builtin_amdgcn_s_setprio(0);
-            ring_push(sh.ready, &sh.ready_tail, fin && !w.rec.hit, wpath, lane, lt_mask);
-            ring_push(sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, wpath, lane, lt_mask);
+            ring_push3(sh.ready, &sh.ready_tail, fin && !w.rec.hit, sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, sh.pending, &sh.pend_tail, false, wpath, lane,
+                       lt_mask);
             if (__ballot(fin)) {
                 n_miss = lds_load(&sh.ready_tail) - lds_load(&sh.ready_head);
                 if (n_miss > PT_PP_QCAP) n_miss = 0;
@@ -1200,6 +1237,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 constexpr bool HITS = decltype(hits_tag)::value;
                 p = HITS ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
                          : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+#ifdef PT_DIAG
+                if (!HITS) { const unsigned long long t = clock64(); dg_sec[0] += t - dg_s; dg_s2 = t; }
+#endif
                 if (p == 0xFFFFFFFFu) return;
                 const uint32_t xy = sh.st[F_XY][p], x = xy & 0xFFFFu, y = xy >> 16;
                 const uint32_t frame_end = sh.st[F_FEND][p], pidx = sh.st[F_PIDX][p];
@@ -1260,6 +1300,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         path_color = path_done ? result : color;
                     }
                 }
+#ifdef PT_DIAG
+                if (!HITS) { const unsigned long long t = clock64(); dg_sec[1] += t - dg_s2; dg_s2 = t; }
+#endif
                 // frame and sample counters of the retiring path (compute.wgsl:112-128); its colour is added below
                 bool frame_ends = false;
                 if (retire) {
@@ -1297,11 +1340,17 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         limit = L.depth;
                         want_aov = (frame == 0 && sample == 0 && L.aov_prim != nullptr);
                     }
+#ifdef PT_DIAG
+                    if (!HITS) { const unsigned long long t = clock64(); dg_sec[2] += t - dg_s2; dg_s2 = t; }
+#endif
                     cn.rays++;
                     // spheres + root visit; a surviving ray goes to PENDING with its first node(s)
                     Walk nw;
                     uint32_t k2 = 0xFFFFFFFFu;
                     const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
+#ifdef PT_DIAG
+                    if (!HITS) { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
+#endif
                     sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
                     sh.st[F_DX][p] = __float_as_uint(cur.d.x); sh.st[F_DY][p] = __float_as_uint(cur.d.y); sh.st[F_DZ][p] = __float_as_uint(cur.d.z);
                     sh.st[F_T][p] = __float_as_uint(nw.rec.t);
@@ -1322,6 +1371,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     to_ready = !need_walk && !nw.rec.hit;
                     to_hit = !need_walk && nw.rec.hit;
                 }
+#ifdef PT_DIAG
+                if (!HITS) { const unsigned long long t = clock64(); dg_sec[4] += t - dg_s2; dg_s2 = t; }
+#endif
                 // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
                 if (retire) {
                     if constexpr (!HITS) path_color = path_color * sky;
@@ -1343,6 +1395,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             };
             if (pass_hits) shading_pass(std::true_type{});
             else shading_pass(std::false_type{});
+#ifdef PT_DIAG
+            if (!pass_hits) { const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
+#endif
             const uint32_t id = p;
             // slots whose job is done take the next one (or die when the launch has no items left)
             if (__ballot(finished) != 0ull) {
@@ -1351,12 +1406,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t n_dead = (uint32_t)__popcll(__ballot(finished && !got));
                 if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
             }
-            ring_push(sh.pending, &sh.pend_tail, to_pending, p, lane, lt_mask);
-            ring_push(sh.ready, &sh.ready_tail, to_ready, p, lane, lt_mask);
-            ring_push(sh.ready_hit, &sh.hit_tail, to_hit, p, lane, lt_mask);
+            ring_push3(sh.pending, &sh.pend_tail, to_pending, sh.ready, &sh.ready_tail, to_ready, sh.ready_hit, &sh.hit_tail, to_hit, p, lane, lt_mask);
             const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
             if (gotm) did_work = true;
 #ifdef PT_DIAG
+            if (!pass_hits) dg_sec[6] += clock64() - dg_s2;
             dg_shades++;
             dg_ready += __popcll(gotm);
             dg_shade_cyc += clock64() - dg_s;
@@ -1389,6 +1443,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             g_diag_marks[(wid & 63u) * 8 + 3] = dg_shades;
             g_diag_marks[(wid & 63u) * 8 + 4] = dg_ready;
             g_diag_marks[(wid & 63u) * 8 + 5] = dg_shade_cyc;
+            for (int k = 0; k < 7; k++) g_diag_marks[512 + (wid & 63u) * 8 + k] = dg_sec[k];
+            for (int k = 0; k < 5; k++) g_diag_marks[1024 + (wid & 63u) * 8 + k] = dg_hist[k];
             g_diag[8 * wid + 3] = dg_shades | (dg_ready << 32);
             g_diag[8 * wid + 4] = dg_shade_cyc;
             g_diag[8 * wid + 5] = dg_steps | (dg_busy << 32);

@@ -49,11 +49,18 @@ if ws is not None:
     srt = np.sort(ws, axis=1)[:, ::-1]
     print("walk steps by rank within the group (most-walking wave first): " + " ".join(f"{v:.0f}" for v in srt.mean(axis=0)))
 
-marks = np.zeros((64, 8), np.uint64)
+marks = np.zeros((192, 8), np.uint64)
 L.pt_diag_read_marks.argtypes = [C.c_void_p, C.c_size_t]
 L.pt_diag_read_marks(marks.ctypes.data_as(C.c_void_p), marks.nbytes)
+sec = marks[64:128].astype(np.float64).sum(axis=0)
+hist = marks[128:].astype(np.float64).sum(axis=0)[:5]
+print("walk steps by busy lanes [1-8, 9-16, 17-32, 33-48, 49-64]: " + " ".join(f"{100 * v / max(hist.sum(), 1):.1f}%" for v in hist))
+marks = marks[:64]
 m = marks.astype(np.float64).sum(axis=0)
 if m[3] > 0:
     hp, hl, hc, ap, al, ac = m[:6]
     print("hit passes %.1f%% of passes: %.1f lanes, %.0f cycles; miss passes: %.1f lanes, %.0f cycles" % (
         100 * hp / ap, hl / max(hp, 1), hc / max(hp, 1), (al - hl) / max(ap - hp, 1), (ac - hc) / max(ap - hp, 1)))
+    nm = max(ap - hp, 1)
+    names = ["pop", "load+sky issue", "counters+new path", "walk_begin", "stores", "deferred sums", "jobs+pushes"]
+    print("miss pass sections (cycles): " + ", ".join(f"{n} {v / nm:.0f}" for n, v in zip(names, sec)))
