@@ -26,6 +26,7 @@ LIB_PATH = os.environ.get("PTRT_LIB", os.path.join(_HERE, "libptrt.so"))  # PTRT
 PT_FLAG_REFERENCE_DISPATCH = 1
 PT_FLAG_AOV = 2
 PT_FLAG_DETAILED_STATS = 4
+PT_FLAG_TILE_KERNEL = 8
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
 

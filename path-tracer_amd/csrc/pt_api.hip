@@ -274,7 +274,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
 int pt_set_flags(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
@@ -485,8 +485,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
     p.aov_t = ctx->aov_t;
     p.counters = ctx->counters;
-    bool use_pool = false;
-    if (const char *env = getenv("PTRT_POOL")) use_pool = atoi(env) != 0;  // tuning aid
+    // The pooled kernel is the default; the per-tile kernel serves PT_FLAG_TILE_KERNEL, depth 0 and
+    // images wider or taller than the pooled kernel's 16-bit pixel coordinates.
+    bool use_pool = !(ctx->flags & PT_FLAG_TILE_KERNEL) && ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
+    if (const char *env = getenv("PTRT_POOL")) use_pool = use_pool && atoi(env) != 0;  // tuning aid: 0 forces the per-tile kernel
     // spill space for traversal stacks deeper than the kernels keep in LDS
     const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
     if (gs) {

@@ -1,0 +1,85 @@
+"""The two implementations of the megakernel -- the pooled one (default) and the one-wave-per-tile one
+(PT_FLAG_TILE_KERNEL, also the fallback for depth 0) -- must produce the same bits: sums, primary-hit
+AOV, ray count and the detailed counters.  The other GPU tests pin the default kernel to the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(pt, scene, w, h, st, sky, flags, calls):
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV | flags)
+    if sky is not None:
+        r.set_sky_cube(sky)
+    for c in calls:
+        if isinstance(c, tuple):
+            r.render_frames(*c)
+        else:
+            r.render(c)
+    out = (r.read_sum().copy(),) + tuple(a.copy() for a in r.read_aov()) + (r.stats(),)
+    r.close()
+    return out
+
+
+def _same(pt, scene, w, h, st, sky, calls, flags=0):
+    a = _render(pt, scene, w, h, st, sky, flags, calls)
+    b = _render(pt, scene, w, h, st, sky, flags | pt.PT_FLAG_TILE_KERNEL, calls)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), \
+        f"sums: {int((a[0].view(np.uint32) != b[0].view(np.uint32)).sum())} of {a[0].size} values differ"
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), "primary-hit AOV differs"
+    assert a[3] == b[3], f"counters differ: {a[3]} vs {b[3]}"
+    return a
+
+
+def _gizmo_scene(pt, scenes):
+    S, M = pt.Sphere, pt.Material
+    spheres = [S((0, 0, -1), 0.5, (0.8, 0.3, 0.3), M.Diffuse), S((1, 0, -1), 0.5, (1, 1, 1), M.Dielectric),
+               S((-1, 0, -1), 0.5, (0.8, 0.6, 0.2), M.Metal), S((0, 1.0, -1), 0.4, (0.2, 0.9, 0.2), M.Gizmo),
+               S((0, -100.5, -1), 100.0, (0.8, 0.8, 0.0), M.Diffuse)]
+    cam = pt.Camera.from_yaw_pitch((0.0, 0.6, 1.8), -90.0, -8.0)
+    return pt.Scene(spheres, scenes.cornell().triangles, cam)
+
+
+@pytest.mark.parametrize("spp,depth", [(1, 8), (3, 5)])
+def test_single_dispatches_match(pt, scenes, spp, depth):
+    """All four compiled variants (spp 1 or more, with and without a gizmo sphere), odd image size."""
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(spp, depth, 1e-4, 1000.0)
+    _same(pt, scenes.cornell(), 100, 59, st, sky, [1, 2, 7])
+    _same(pt, _gizmo_scene(pt, scenes), 100, 59, st, sky, [3, 4])
+
+
+def test_fused_frames_match(pt, scenes):
+    """Fused launches on a mesh with a deep tree.  Short launches add every frame in order: same bits.
+    Long ones are split into work items by measured cost, which the two kernels measure differently,
+    so their partial sums are grouped differently: same rays, sums equal up to summation order."""
+    scene = scenes.bunny(n=24)
+    sky = scenes.sky_cube_direct(32)
+    st = pt.Settings(1, 8, 1e-4, 1000.0)
+    a = _same(pt, scene, 192, 108, st, sky, [(1, 1, 5), (6, 1, 15), (100, 3, 9)])
+    assert (a[0][..., 3] == 29).all() and a[3]["frames"] == 29
+    calls = [(1, 1, 5), (6, 1, 40), (100, 3, 40)]
+    p = _render(pt, scene, 192, 108, st, sky, 0, calls)
+    t = _render(pt, scene, 192, 108, st, sky, pt.PT_FLAG_TILE_KERNEL, calls)
+    assert p[3] == t[3] and np.array_equal(p[1], t[1]) and np.array_equal(p[0][..., 3], t[0][..., 3]) and (p[0][..., 3] == 85).all()
+    np.testing.assert_allclose(p[0], t[0], rtol=85 * 2.0 ** -23, atol=1e-6)
+    p2 = _render(pt, scene, 192, 108, st, sky, 0, calls)
+    assert np.array_equal(p[0].view(np.uint32), p2[0].view(np.uint32)), "pooled kernel is not reproducible run to run"
+
+
+def test_detailed_stats_and_reference_dispatch_match(pt, scenes):
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(2, 6, 1e-4, 1000.0)
+    a = _same(pt, _gizmo_scene(pt, scenes), 100, 59, st, sky, [5, (6, 1, 12)], flags=pt.PT_FLAG_DETAILED_STATS | pt.PT_FLAG_REFERENCE_DISPATCH)
+    assert a[3]["interior"] > 0 and a[3]["tri_tests"] > 0 and a[3]["sky_lookups"] > 0
+    assert (a[0][48:] == 0).all() and (a[0][:, 96:] == 0).all()  # outside floor(w/16)*16 x floor(h/16)*16
+
+
+def test_depth_zero_uses_the_tile_kernel(pt, po, scenes):
+    """depth 0: no ray is ever traced and every path is white (compute.wgsl:131-137, 203)."""
+    st = pt.Settings(2, 0, 1e-4, 1000.0)
+    r = pt.Renderer(scenes.cornell(), 40, 24, settings=st)
+    r.render_frames(1, 1, 3)
+    s = r.read_sum()
+    assert (s[..., :3] == 3.0).all() and (s[..., 3] == 3.0).all() and r.stats()["rays"] == 0
+    r.close()

@@ -3,7 +3,19 @@ import csv
 import glob
 import os
 import sys
+import re
 from collections import defaultdict
+
+
+def is_mega(name):
+    return "trace_kernel" in name or "pool_kernel" in name
+
+
+def is_planned(name):
+    """Planned launches (item table + partial sums): the kernels' last template argument, DIRECT, is false."""
+    m = re.search(r"_kernel<([^>]*)>", name)
+    return bool(m) and m.group(1).split(",")[-1].strip() == "false"
+
 
 root = sys.argv[1]
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
@@ -11,18 +23,19 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recur
     for row in csv.DictReader(open(f)):
         print("  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:60], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r.get("Kernel_Name", "")]
+    rows = [r for r in csv.DictReader(open(f)) if is_mega(r.get("Kernel_Name", ""))]
     if rows:
-        print("== trace_kernel dispatches (ms): " + ", ".join("%s %.2f" % ("planned" if r["Kernel_Name"].rstrip(">)(PtTraceParams ").endswith("false") else "direct", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in rows))
+        print("== megakernel dispatches (ms): " + ", ".join("%s %.2f" % ("planned" if is_planned(r["Kernel_Name"]) else "direct", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in rows))
         r = rows[-1]
-        print("== last trace_kernel dispatch: VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s dur_ns=%d" % (
+        print("== last megakernel dispatch: VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s dur_ns=%d" % (
             r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"),
             int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-print("== pmc (per trace_kernel dispatch, mean over dispatches)")
+print("== pmc (per megakernel dispatch, planned launches only, mean over dispatches)")
 for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     acc, n = defaultdict(float), defaultdict(int)
     for row in csv.DictReader(open(f)):
-        if "trace_kernel" not in row.get("Kernel_Name", ""):
+        kn = row.get("Kernel_Name", "")
+        if not (is_mega(kn) and is_planned(kn) and "_kernel<false" in kn):  # planned launches of the plain (no detailed stats) build
             continue
         acc[row["Counter_Name"]] += float(row["Counter_Value"])
         n[row["Counter_Name"]] += 1
@@ -37,7 +50,7 @@ vals = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     xs = []
     for f in glob.glob(os.path.join(root, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
-        xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "trace_kernel<false" in r.get("Kernel_Name", "") and "false>" in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
+        xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if is_mega(r.get("Kernel_Name", "")) and is_planned(r["Kernel_Name"]) and "_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == name]
     big = [x for x in xs if x > 0.5 * max(xs)] if xs else []
     vals[name] = sum(big) / len(big) if big else None
 if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
