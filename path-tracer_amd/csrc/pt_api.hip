@@ -513,10 +513,13 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.sorted = ctx->tile_sorted;
     sch.tile_items = ctx->tile_items;
     sch.cost_valid = &ctx->cost_valid;
-    uint32_t per_slot = 12;
+    // pooled kernel: a pixel's frames run one after the other, so costly tiles need short items
+    uint32_t per_slot = use_pool ? 44 : 12;
     if (const char *env = getenv("PTRT_ITEMS_PER_SLOT")) per_slot = (uint32_t)atoi(env);  // tuning aid
     sch.wanted_items = ctx->resident_waves * per_slot;
     sch.default_chunk = 32;
+    sch.max_chunk = 0;
+    if (const char *env = getenv("PTRT_MAX_CHUNK")) sch.max_chunk = (uint32_t)atoi(env);  // tuning aid
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid

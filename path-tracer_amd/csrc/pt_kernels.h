@@ -77,6 +77,7 @@ struct PtSchedule {
     bool *cost_valid;      // host flag: cost holds a measurement of this image
     uint32_t wanted_items;        // work items a plan aims for (a multiple of the resident-wave capacity)
     uint32_t default_chunk;       // frames per item when there is no measurement to plan from
+    uint32_t max_chunk;           // most frames a planned item may hold (0: no limit)
     uint32_t min_planned_frames;  // shorter launches run one item per tile (exact sequential sums)
     uint32_t probe_frames;        // frames rendered directly to obtain the first measurement
     bool use_pool;                // pooled kernel (persistent workgroups, paths and rays pooled in LDS)

@@ -815,6 +815,7 @@ struct PPFields {
     static constexpr uint32_t COUNT = IDIR + (GIZMO ? 4u : 0u);
 };
 
+typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
 // Ring entries are slot id + 1 in 16 bits.
 typedef uint16_t pp_entry;
 __device__ __forceinline__ uint32_t ring_load(pp_entry *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -834,7 +835,7 @@ struct PPShared {
     uint32_t job_word;           // generation << 8 | pixels handed out (64 = all)
     uint32_t job_lock;           // held by the lane that opens the next item
     uint32_t no_more;            // the launch's item counter is exhausted
-    uint32_t it_x0, it_y0, it_fb, it_fend, it_index;
+    pp_u32x4 item;               // x0 | y0 << 16, first frame, end frame, item index (read after an acquire fence)
 };
 
 // Hand-shake words are accessed with relaxed workgroup-scope atomics (plain ds_read/ds_write that the
@@ -1005,8 +1006,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     const uint32_t done = jw & 0xFFu;
                     if (done < 64u) {
                         // read the item first, claim second: the claim fails if the item was replaced meanwhile
-                        x0 = lds_load(&sh.it_x0); y0 = lds_load(&sh.it_y0); fb = lds_load(&sh.it_fb); fend = lds_load(&sh.it_fend);
-                        index = lds_load(&sh.it_index);
+                        const pp_u32x4 rec = sh.item;  // one 16-byte LDS read
+                        x0 = rec.x & 0xFFFFu; y0 = rec.x >> 16; fb = rec.y; fend = rec.z; index = rec.w;
                         const uint32_t t = min((uint32_t)__popcll(nm), 64u - done);
                         if (atomicCAS(&sh.job_word, jw, jw + t) == jw) { first = done; take = t; break; }
                         continue;
@@ -1028,8 +1029,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             lds_store(&sh.no_more, 1u);
                         } else {
                             const uint32_t tby = tile / L.tiles_x, tbx = tile - tby * L.tiles_x;
-                            lds_store(&sh.it_x0, tbx * PT_TILE); lds_store(&sh.it_y0, tby * PT_TILE);
-                            lds_store(&sh.it_fb, f0); lds_store(&sh.it_fend, f0 + fc); lds_store(&sh.it_index, it);
+                            sh.item = pp_u32x4{(tbx * PT_TILE) | ((tby * PT_TILE) << 16), f0, f0 + fc, it};
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             lds_store(&sh.job_word, ((jw >> 8) + 1u) << 8);
                         }
@@ -1493,13 +1493,15 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
 
 // Plans the next launch from the wave time each tile cost in the previous one: tiles sorted
 // costliest first (1024 linear buckets; ties in arbitrary order), each split into
-// ceil(cost / target) items of consecutive frames, target = total cost / wanted item count.
+// ceil(cost / target) items of consecutive frames, target = total cost / wanted item count, and into
+// at least ceil(n_frames / max_chunk) items (a pixel's frames run one after the other, so an item's
+// frame count bounds how long it takes no matter how cheap its tile is).
 // Without cost data (first launch) every tile gets ceil(n_frames / default_chunk) items.
 // The plan only affects scheduling and the (fixed, per-plan) order of partial sums.
 // One workgroup.  tile_items[t] = (first item, item count); clears cost for the next measurement.
 __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_tiles, uint32_t n_frames, uint32_t wanted_items,
-                                                    uint32_t default_chunk, uint4 *items, uint32_t item_cap, uint2 *tile_items,
-                                                    uint32_t *sorted)
+                                                    uint32_t default_chunk, uint32_t max_chunk, uint4 *items, uint32_t item_cap,
+                                                    uint2 *tile_items, uint32_t *sorted)
 {
     __shared__ uint32_t hist[1024];
     __shared__ unsigned long long total;
@@ -1538,6 +1540,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_t
         if (j < n_tiles) {
             t = sorted[j];
             n = have_cost ? (uint32_t)ceilf((float)cost[t] / target) : uniform_items;
+            if (max_chunk) n = max(n, (n_frames + max_chunk - 1u) / max_chunk);
             n = min(max(n, 1u), n_frames);
         }
         // block-wide exclusive scan of n (reuse hist)
@@ -1717,7 +1720,8 @@ uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height)
 uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule &sch)
 {
     const uint64_t uniform = (uint64_t)n_tiles * ((n_frames + std::max(sch.default_chunk, 1u) - 1u) / std::max(sch.default_chunk, 1u));
-    const uint64_t planned = (uint64_t)n_tiles + sch.wanted_items + 1024u;
+    const uint64_t capped = sch.max_chunk ? (uint64_t)n_tiles * ((n_frames + sch.max_chunk - 1u) / sch.max_chunk) : 0;
+    const uint64_t planned = (uint64_t)n_tiles + sch.wanted_items + capped + 1024u;
     return (uint32_t)std::min<uint64_t>(std::max(uniform, planned), 0x7FFFFFFFull);
 }
 
@@ -1761,7 +1765,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
     if (cap > sch.item_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk,
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk,
                        sch.items, cap, sch.tile_items, sch.sorted);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     p.items = sch.items;
