@@ -44,8 +44,10 @@ typedef enum pt_status {
                                          dispatch_workgroups(w/16, h/16, 1) does (renderer.rs:565-569) */
 #define PT_FLAG_AOV 2u                /* record the primary hit of each pixel's first sample */
 #define PT_FLAG_DETAILED_STATS 4u     /* count node steps / triangle tests too (slower kernel) */
-#define PT_FLAG_TILE_KERNEL 8u        /* render with the one-wave-per-tile kernel instead of the pooled one
-                                         (same image bit for bit; kept as the second implementation) */
+/* Two implementations of the megakernel give the same image bit for bit (short launches) or up to fp32
+   summation order (fused launches of 16 frames or more).  By default the library picks by mesh size. */
+#define PT_FLAG_TILE_KERNEL 8u        /* always the one-wave-per-tile kernel */
+#define PT_FLAG_POOL_KERNEL 16u       /* always the pooled kernel (where it can run: depth >= 1, image <= 65535^2) */
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */
 #define PT_PRIM_NONE 0xFFFFFFFFu      /* miss */

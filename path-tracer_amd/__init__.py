@@ -27,6 +27,7 @@ PT_FLAG_REFERENCE_DISPATCH = 1
 PT_FLAG_AOV = 2
 PT_FLAG_DETAILED_STATS = 4
 PT_FLAG_TILE_KERNEL = 8
+PT_FLAG_POOL_KERNEL = 16
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
 

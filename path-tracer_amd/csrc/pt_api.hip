@@ -59,6 +59,7 @@ struct pt_ctx {
     uint32_t *pool_gstack = nullptr;
     size_t pool_gstack_bytes = 0;
     uint32_t n_cus = 256;
+    uint32_t n_tri_slots = 0;
 
     // work-item planning (see plan_kernel)
     uint32_t *tile_cost = nullptr, *tile_sorted = nullptr, *next_item = nullptr;
@@ -136,6 +137,7 @@ void free_mesh(pt_ctx *ctx)
     dev_free(ctx->tri_pos);
     dev_free(ctx->tri_nrm);
     ctx->n_nodes = 0;
+    ctx->n_tri_slots = 0;
     ctx->root_token = 0;
     ctx->bvh_depth = 0;
 }
@@ -274,7 +276,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
 int pt_set_flags(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
@@ -355,6 +357,7 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
     PT_HIP(ctx, hipMemcpy(ctx->tri_pos, h_pos.data(), h_pos.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->tri_nrm, h_nrm.data(), h_nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
     ctx->n_nodes = n_nodes;
+    ctx->n_tri_slots = n_idx;
     ctx->root_token = token_of(0);
     if (nodes[0].triangle_count == 0)
         for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
@@ -485,10 +488,20 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
     p.aov_t = ctx->aov_t;
     p.counters = ctx->counters;
-    // The pooled kernel is the default; the per-tile kernel serves PT_FLAG_TILE_KERNEL, depth 0 and
-    // images wider or taller than the pooled kernel's 16-bit pixel coordinates.
-    bool use_pool = !(ctx->flags & PT_FLAG_TILE_KERNEL) && ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
-    if (const char *env = getenv("PTRT_POOL")) use_pool = use_pool && atoi(env) != 0;  // tuning aid: 0 forces the per-tile kernel
+    // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
+    // global memory) and wins when BVH walks are long, i.e. on big meshes; measured on this GPU
+    // (tools/kernel_choice.py) the per-tile kernel is faster up to ~12k triangles and the pooled one from
+    // ~70k on (3.7x at 10 M), so the switch is the triangle count.  Flags or PTRT_KERNEL force either;
+    // depth 0 and images wider or taller than 65535 always take the per-tile kernel.
+    const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
+    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES;
+    if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
+    if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
+    if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags
+        if (env[0] == 'p') use_pool = true;
+        else if (env[0] == 't') use_pool = false;
+    }
+    use_pool = use_pool && pool_possible;
     // spill space for traversal stacks deeper than the kernels keep in LDS
     const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
     if (gs) {
@@ -519,6 +532,8 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.wanted_items = ctx->resident_waves * per_slot;
     sch.default_chunk = 32;
     sch.max_chunk = 0;
+    sch.min_chunk = use_pool ? 8 : 1;
+    if (const char *env = getenv("PTRT_MIN_CHUNK")) sch.min_chunk = (uint32_t)atoi(env);  // tuning aid
     if (const char *env = getenv("PTRT_MAX_CHUNK")) sch.max_chunk = (uint32_t)atoi(env);  // tuning aid
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;

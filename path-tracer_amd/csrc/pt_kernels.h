@@ -14,6 +14,7 @@
 #define PT_TRACE_WAVES_PER_EU 5   // register budget of the megakernel: 512 / 5 -> at most 96 VGPRs
 #endif
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
+#define PT_POOL_MIN_TRIANGLES 32768u  // meshes from this size on are rendered by the pooled kernel
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
@@ -78,6 +79,7 @@ struct PtSchedule {
     uint32_t wanted_items;        // work items a plan aims for (a multiple of the resident-wave capacity)
     uint32_t default_chunk;       // frames per item when there is no measurement to plan from
     uint32_t max_chunk;           // most frames a planned item may hold (0: no limit)
+    uint32_t min_chunk;           // fewest frames a planned item may hold
     uint32_t min_planned_frames;  // shorter launches run one item per tile (exact sequential sums)
     uint32_t probe_frames;        // frames rendered directly to obtain the first measurement
     bool use_pool;                // pooled kernel (persistent workgroups, paths and rays pooled in LDS)

@@ -1495,12 +1495,14 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
 // costliest first (1024 linear buckets; ties in arbitrary order), each split into
 // ceil(cost / target) items of consecutive frames, target = total cost / wanted item count, and into
 // at least ceil(n_frames / max_chunk) items (a pixel's frames run one after the other, so an item's
-// frame count bounds how long it takes no matter how cheap its tile is).
+// frame count bounds how long it takes no matter how cheap its tile is), but never into items of fewer
+// than min_chunk frames (every item has a fixed cost: a partial-sum row, a job hand-out per pixel).
 // Without cost data (first launch) every tile gets ceil(n_frames / default_chunk) items.
 // The plan only affects scheduling and the (fixed, per-plan) order of partial sums.
 // One workgroup.  tile_items[t] = (first item, item count); clears cost for the next measurement.
 __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_tiles, uint32_t n_frames, uint32_t wanted_items,
-                                                    uint32_t default_chunk, uint32_t max_chunk, uint4 *items, uint32_t item_cap,
+                                                    uint32_t default_chunk, uint32_t max_chunk, uint32_t min_chunk, uint4 *items,
+                                                    uint32_t item_cap,
                                                     uint2 *tile_items, uint32_t *sorted)
 {
     __shared__ uint32_t hist[1024];
@@ -1541,7 +1543,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_t
             t = sorted[j];
             n = have_cost ? (uint32_t)ceilf((float)cost[t] / target) : uniform_items;
             if (max_chunk) n = max(n, (n_frames + max_chunk - 1u) / max_chunk);
-            n = min(max(n, 1u), n_frames);
+            n = min(max(n, 1u), max(n_frames / max(min_chunk, 1u), 1u));
         }
         // block-wide exclusive scan of n (reuse hist)
         hist[tid] = n;
@@ -1765,7 +1767,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
     if (cap > sch.item_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk,
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk, sch.min_chunk,
                        sch.items, cap, sch.tile_items, sch.sorted);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     p.items = sch.items;

@@ -15,6 +15,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_generate_tests(metafunc):
+    """Every GPU test runs twice: once with the pooled megakernel forced, once with the per-tile one
+    (the library itself picks by mesh size, which would leave one of them untested on small scenes)."""
+    own = hasattr(metafunc.module, "megakernel")  # a module that picks kernels itself overrides the fixture
+    if metafunc.definition.get_closest_marker("gpu") is not None and "megakernel" in metafunc.fixturenames and not own:
+        metafunc.parametrize("megakernel", ["pool", "tile"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def megakernel(request):
+    kind = getattr(request, "param", None)
+    if kind is None:
+        yield None
+        return
+    old = os.environ.get("PTRT_KERNEL")
+    os.environ["PTRT_KERNEL"] = kind  # read by the library at every render call
+    yield kind
+    if old is None:
+        os.environ.pop("PTRT_KERNEL", None)
+    else:
+        os.environ["PTRT_KERNEL"] = old
+
+
 def _ensure_built():
     """The .so files are built by __graft_entry__.build() and travel with the tree; this only
     covers a fresh checkout on a machine with the toolchain."""

@@ -1,10 +1,22 @@
-"""The two implementations of the megakernel -- the pooled one (default) and the one-wave-per-tile one
-(PT_FLAG_TILE_KERNEL, also the fallback for depth 0) -- must produce the same bits: sums, primary-hit
-AOV, ray count and the detailed counters.  The other GPU tests pin the default kernel to the oracle."""
+"""The two implementations of the megakernel -- the pooled one (PT_FLAG_POOL_KERNEL) and the
+one-wave-per-tile one (PT_FLAG_TILE_KERNEL, also the fallback for depth 0) -- must produce the same bits:
+sums, primary-hit AOV, ray count and the detailed counters.  The other GPU tests pin each of them to the
+oracle (tests/conftest.py runs every GPU test once per kernel)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def megakernel():
+    """These tests choose the kernel themselves, through the flags."""
+    old = os.environ.pop("PTRT_KERNEL", None)
+    yield None
+    if old is not None:
+        os.environ["PTRT_KERNEL"] = old
 
 
 def _render(pt, scene, w, h, st, sky, flags, calls):
@@ -22,7 +34,7 @@ def _render(pt, scene, w, h, st, sky, flags, calls):
 
 
 def _same(pt, scene, w, h, st, sky, calls, flags=0):
-    a = _render(pt, scene, w, h, st, sky, flags, calls)
+    a = _render(pt, scene, w, h, st, sky, flags | pt.PT_FLAG_POOL_KERNEL, calls)
     b = _render(pt, scene, w, h, st, sky, flags | pt.PT_FLAG_TILE_KERNEL, calls)
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), \
         f"sums: {int((a[0].view(np.uint32) != b[0].view(np.uint32)).sum())} of {a[0].size} values differ"
@@ -59,11 +71,11 @@ def test_fused_frames_match(pt, scenes):
     a = _same(pt, scene, 192, 108, st, sky, [(1, 1, 5), (6, 1, 15), (100, 3, 9)])
     assert (a[0][..., 3] == 29).all() and a[3]["frames"] == 29
     calls = [(1, 1, 5), (6, 1, 40), (100, 3, 40)]
-    p = _render(pt, scene, 192, 108, st, sky, 0, calls)
+    p = _render(pt, scene, 192, 108, st, sky, pt.PT_FLAG_POOL_KERNEL, calls)
     t = _render(pt, scene, 192, 108, st, sky, pt.PT_FLAG_TILE_KERNEL, calls)
     assert p[3] == t[3] and np.array_equal(p[1], t[1]) and np.array_equal(p[0][..., 3], t[0][..., 3]) and (p[0][..., 3] == 85).all()
     np.testing.assert_allclose(p[0], t[0], rtol=85 * 2.0 ** -23, atol=1e-6)
-    p2 = _render(pt, scene, 192, 108, st, sky, 0, calls)
+    p2 = _render(pt, scene, 192, 108, st, sky, pt.PT_FLAG_POOL_KERNEL, calls)
     assert np.array_equal(p[0].view(np.uint32), p2[0].view(np.uint32)), "pooled kernel is not reproducible run to run"
 
 
@@ -78,8 +90,20 @@ def test_detailed_stats_and_reference_dispatch_match(pt, scenes):
 def test_depth_zero_uses_the_tile_kernel(pt, po, scenes):
     """depth 0: no ray is ever traced and every path is white (compute.wgsl:131-137, 203)."""
     st = pt.Settings(2, 0, 1e-4, 1000.0)
-    r = pt.Renderer(scenes.cornell(), 40, 24, settings=st)
+    r = pt.Renderer(scenes.cornell(), 40, 24, settings=st, flags=pt.PT_FLAG_POOL_KERNEL)
     r.render_frames(1, 1, 3)
     s = r.read_sum()
     assert (s[..., :3] == 3.0).all() and (s[..., 3] == 3.0).all() and r.stats()["rays"] == 0
     r.close()
+
+
+def test_automatic_choice_by_mesh_size(pt, scenes):
+    """Without flags the library takes the per-tile kernel for small meshes and the pooled one for big ones;
+    either way the image is the same as with the kernel forced."""
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(1, 4, 1e-4, 1000.0)
+    for n in (4, 76):  # 192 and 69 312 triangles
+        scene = scenes.bunny(n=n)
+        auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 6)])
+        forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_TILE_KERNEL, [(1, 1, 6)])
+        assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): per-wave section counters of the pooled kernel from the PT_DIAG build.
-Run: PTRT_POOL=1 PTRT_LIB=path-tracer_amd/libptrt_diag.so python tools/diag_pool.py [frames]"""
+Run: PTRT_LIB=path-tracer_amd/libptrt_diag.so python tools/diag_pool.py [frames]"""
 import ctypes as C
 import importlib
 import os

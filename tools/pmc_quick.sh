@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: two SQ counter passes over a short bench run; prints per-dispatch means for the main kernel.
-# Usage: [PTRT_POOL=1] bash tools/pmc_quick.sh <tag>
+# Usage: [PTRT_KERNEL=pool|tile] bash tools/pmc_quick.sh <tag>
 set -o pipefail
 TAG=${1:-q}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcq_$TAG

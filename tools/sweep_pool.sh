@@ -1,6 +1,5 @@
 #!/bin/bash
 # GPU box: sweep the pooled kernel's scheduling knobs (environment overrides) with short bench runs.
-export PTRT_POOL=1
 run() { echo -n "$* -> "; env "$@" timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.0f Mrays/s %.2f ms" % (d["value"], d["ms_per_step"]))' || exit 1; }
 run X=0
 for v in 8 16 32; do run PTRT_POOL_STEPS=$v; done
