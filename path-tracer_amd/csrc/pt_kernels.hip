@@ -646,7 +646,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     // only runs the shading block once enough lanes wait for it (or nobody is walking).
     enum : uint32_t { M_SHADE = 0, M_WALK = 1, M_DONE = 2 };
     uint32_t mode = active ? M_SHADE : M_DONE;
-    Walk w;
+    WalkU w;
     w.rec.hit = w.rec.is_tri = false;
     w.rec.t = w.rec.u = w.rec.v = 0.0f;
     w.rec.index = 0;
@@ -654,6 +654,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     w.nearest = 9999.0f;
     w.node = 0;
     w.sp = 0;
+    w.leaf_next = w.leaf_left = 0;
 
     for (;;) {
         const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
@@ -687,6 +688,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
                 if (active) {
                     cn.rays++;
                     mode = walk_begin<STATS>(sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
+                    w.leaf_left = 0;
+                    if (mode == M_WALK) walk_enter(w);
                 } else {
                     mode = M_DONE;
                 }
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
             g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (mode == M_WALK) {
-            if (walk_step<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
+            if (walk_step_u<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
         }
 #ifdef PT_DIAG
         { const unsigned long long t = clock64(); diag_a += t - diag_s; }

@@ -11,7 +11,7 @@ st = pt.Settings(1, 8, 1e-4, 1000.0)
 for n in [int(a) for a in sys.argv[1:]] or [2, 4, 8, 16, 32, 76]:
     scene = scenes.bunny(n=n)
     res = []
-    for flags in (0, pt.PT_FLAG_TILE_KERNEL):
+    for flags in (pt.PT_FLAG_POOL_KERNEL, pt.PT_FLAG_TILE_KERNEL):
         r = pt.Renderer(scene, 1920, 1080, settings=st, flags=flags)
         r.set_sky_cube(sky)
         r.render_frames(1, 1, 64); r.sync()
