@@ -36,7 +36,8 @@ typedef enum pt_status {
     PT_ERR_HIP = -2,       /* a HIP runtime call failed; message carries hipGetErrorString */
     PT_ERR_NOMEM = -3,     /* host or device allocation failed */
     PT_ERR_STATE = -4,     /* call not valid in the context's current state */
-    PT_ERR_LIMIT = -5      /* input exceeds a documented limit */
+    PT_ERR_LIMIT = -5,     /* input exceeds a documented limit */
+    PT_ERR_INTERNAL = -6   /* a kernel reported a defect in itself (never expected; the image is incomplete) */
 } pt_status;
 
 /* pt_set_flags bits */

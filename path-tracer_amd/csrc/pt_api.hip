@@ -216,6 +216,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     ctx->n_tiles = (uint32_t)n_tiles;
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_cost, n_tiles * sizeof(uint32_t)), "tile cost");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->next_item, 256), "item counter");
+    if (rc == PT_OK) step(hipMemset(ctx->next_item, 0, 256), "clear");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sorted, n_tiles * sizeof(uint32_t)), "tile order");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_items, n_tiles * sizeof(uint2)), "tile items");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
@@ -601,14 +602,27 @@ int pt_reset(pt_ctx *ctx)
     PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
     ctx->frames = 0;
     ctx->paths = 0;
+    PT_HIP(ctx, hipMemsetAsync(ctx->next_item + 1, 0, sizeof(uint32_t), ctx->stream));
     return PT_OK;
 }
+
+namespace {
+// After a synchronisation: did a wave of the pooled kernel give up waiting on a hand-shake (its bounded
+// waits exist so that a defect cannot hang the GPU)?  The image is then incomplete.
+int check_gave_up(pt_ctx *ctx)
+{
+    uint32_t gave_up = 0;
+    PT_HIP(ctx, hipMemcpy(&gave_up, ctx->next_item + 1, sizeof gave_up, hipMemcpyDeviceToHost));
+    if (gave_up) return fail(ctx, PT_ERR_INTERNAL, "pooled kernel: %u waves gave up waiting; the accumulated image is incomplete (pt_reset and use PT_FLAG_TILE_KERNEL)", gave_up);
+    return PT_OK;
+}
+}  // namespace
 
 int pt_sync(pt_ctx *ctx)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return check_gave_up(ctx);
 }
 
 int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
@@ -617,7 +631,7 @@ int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_sum_rgba32f: null output");
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(out, ctx->accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
-    return PT_OK;
+    return check_gave_up(ctx);
 }
 
 int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
@@ -630,7 +644,7 @@ int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
     PT_HIP(ctx, pt_launch_resolve(ctx->accum, n, static_cast<float4 *>(ctx->scratch), nullptr, 0, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(out, ctx->scratch, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    return PT_OK;
+    return check_gave_up(ctx);
 }
 
 int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
@@ -643,7 +657,7 @@ int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
     PT_HIP(ctx, pt_launch_resolve(ctx->accum, n, nullptr, static_cast<uint32_t *>(ctx->scratch), 1, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PT_HIP(ctx, hipMemcpy(out, ctx->scratch, (size_t)n * 4u, hipMemcpyDeviceToHost));
-    return PT_OK;
+    return check_gave_up(ctx);
 }
 
 int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
@@ -674,7 +688,7 @@ int pt_stats(pt_ctx *ctx, pt_stats_t *out)
     out->sphere_accept = c[8];
     out->frames = ctx->frames;
     out->bvh_depth = ctx->bvh_depth;
-    return PT_OK;
+    return check_gave_up(ctx);
 }
 
 void *pt_accum_device_ptr(pt_ctx *ctx) { return ctx ? ctx->accum : nullptr; }

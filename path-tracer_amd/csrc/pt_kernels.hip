@@ -1456,8 +1456,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         }
     }
 #endif
-    // a wave that gave up (should never happen) leaves a mark instead of hanging the GPU
-    if ((__ballot(wbusy) != 0ull || lds_load(&sh.live) != 0u) && lane == 0) atomicAdd(&P.counters[PT_NUM_COUNTERS - 1], 1ull << 48);
+    // a wave that gave up (should never happen) leaves a mark for the host instead of hanging the GPU
+    if ((__ballot(wbusy) != 0ull || lds_load(&sh.live) != 0u) && lane == 0) atomicAdd(P.next_item + 1, 1u);
 
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 1;
