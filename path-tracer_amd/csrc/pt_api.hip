@@ -164,6 +164,7 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
 int ensure_gstack(pt_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->gstack_bytes) return PT_OK;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a launch in flight may still use the old buffer
     dev_free(ctx->gstack);
     ctx->gstack_bytes = 0;
     PT_HIP(ctx, hipMalloc((void **)&ctx->gstack, bytes));
@@ -504,13 +505,6 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     use_pool = use_pool && pool_possible;
     // spill space for traversal stacks deeper than the kernels keep in LDS
-    const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth);
-    if (gs) {
-        int rc = ensure_gstack(ctx, gs);
-        if (rc != PT_OK) return rc;
-    }
-    p.gstack = ctx->gstack;
-    p.gstack_cap = gs ? ctx->bvh_depth : 0;
     const size_t pgs = use_pool ? pt_pool_gstack_bytes(ctx->n_cus, ctx->bvh_depth) : 0;
     if (pgs > ctx->pool_gstack_bytes) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -519,7 +513,9 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         PT_HIP(ctx, hipMalloc((void **)&ctx->pool_gstack, pgs));
         ctx->pool_gstack_bytes = pgs;
     }
-    p.refill_lanes = use_pool ? 64 : 48;
+    // per-tile kernel: lanes that must wait for shading before the wave runs a shading pass; long walks
+    // (big meshes) favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s)
+    p.refill_lanes = use_pool ? 64 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48);
     if (const char *env = getenv("PTRT_REFILL_LANES")) p.refill_lanes = (uint32_t)atoi(env);  // tuning aid
 
     PtSchedule sch{};
@@ -528,9 +524,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.tile_items = ctx->tile_items;
     sch.cost_valid = &ctx->cost_valid;
     // pooled kernel: a pixel's frames run one after the other, so costly tiles need short items
-    uint32_t per_slot = use_pool ? 44 : 12;
+    uint32_t per_slot = use_pool ? 44 : 2;  // per-tile kernel: every item costs a wave its start-up and its ragged end
     if (const char *env = getenv("PTRT_ITEMS_PER_SLOT")) per_slot = (uint32_t)atoi(env);  // tuning aid
     sch.wanted_items = ctx->resident_waves * per_slot;
+    if (const char *env = getenv("PTRT_WANTED_ITEMS")) sch.wanted_items = (uint32_t)atoi(env);  // tuning aid
     sch.default_chunk = 32;
     sch.max_chunk = 0;
     sch.min_chunk = use_pool ? 8 : 1;
@@ -568,8 +565,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         const uint32_t batch = std::min(n_frames - done, max_frames);
         p.time0 = time0 + done * stride;
         p.n_frames = batch;
-        if (batch >= sch.min_planned_frames && (use_pool || !pt_trace_gstack_bytes(ctx->width, ctx->height, ctx->bvh_depth))) {
+        uint32_t blocks = ctx->n_tiles;
+        if (batch >= sch.min_planned_frames) {
             const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, sch);
+            blocks = std::max(blocks, cap);
             if (cap > ctx->item_cap) {
                 PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 dev_free(ctx->items);
@@ -583,6 +582,15 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         sch.items = ctx->items;
         sch.partial = ctx->partial;
         sch.item_cap = ctx->item_cap;
+        // spill space for traversal stacks deeper than the per-tile kernel keeps in LDS
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->bvh_depth);
+        if (gs) {
+            int rc = ensure_gstack(ctx, gs);
+            if (rc != PT_OK) return rc;
+        }
+        p.gstack = ctx->gstack;
+        p.gstack_cap = gs ? ctx->bvh_depth : 0;
+        p.gstack_blocks = gs ? blocks : 0;
         PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
         done += batch;
         ctx->frames += batch;

@@ -55,7 +55,8 @@ struct PtTraceParams {
     float *aov_t;
     unsigned long long *counters;  // PT_NUM_COUNTERS
     uint32_t *gstack;              // global-memory traversal stack (deep trees only)
-    uint32_t gstack_cap;
+    uint32_t gstack_cap;           // deepest stack the buffer is sized for
+    uint32_t gstack_blocks;        // workgroups (of the per-tile kernel) the buffer has columns for
     // pooled kernel only (filled in by pt_launch_trace)
     uint32_t *next_item;           // work-item counter, zero at launch
     uint32_t n_items;
@@ -94,8 +95,8 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
 uint32_t pt_trace_num_tiles(uint32_t width, uint32_t height);
 // Item-table entries a launch of n_frames can need.
 uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule &sch);
-// Bytes of global stack pt_launch_trace needs for this image/tree, 0 if the LDS stack suffices.
-size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth);
+// Bytes of global stack the per-tile kernel needs for a grid of n_blocks and this tree, 0 if the LDS stack suffices.
+size_t pt_trace_gstack_bytes(uint32_t n_blocks, uint32_t stack_depth);
 // Same for the pooled kernel (PtSchedule::pool_gstack).
 size_t pt_pool_gstack_bytes(uint32_t n_cus, uint32_t stack_depth);
 

@@ -1646,10 +1646,9 @@ __global__ __launch_bounds__(256) void equirect_kernel(const float4 *src, uint32
 
 static size_t spill_entries(uint32_t stack_depth) { return stack_depth > PT_LDS_STACK ? stack_depth - PT_LDS_STACK : 0; }
 
-size_t pt_trace_gstack_bytes(uint32_t width, uint32_t height, uint32_t stack_depth)
+size_t pt_trace_gstack_bytes(uint32_t n_blocks, uint32_t stack_depth)
 {
-    const size_t bx = (width + PT_TILE - 1u) / PT_TILE, by = (height + PT_TILE - 1u) / PT_TILE;
-    return bx * by * PT_TRACE_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
+    return (size_t)n_blocks * PT_TRACE_BLOCK * spill_entries(stack_depth) * sizeof(uint32_t);
 }
 
 static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool overflow, bool detailed_stats, hipStream_t stream)
@@ -1738,14 +1737,14 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     if (p.n_tiles == 0 || p.n_frames == 0) return hipSuccess;
     const bool overflow = spill_entries(stack_depth) > 0;
     p.cost = nullptr;
-    // Few frames, no scheduling buffers, or a spilling stack (whose buffer has one column per tile
-    // lane): one item per tile, frames added in order onto the stored sums.
+    // Few frames or no scheduling buffers: one item per tile, frames added in order onto the stored sums.
     // The pooled kernel has its own (shorter) LDS stack and spill buffer.
     const bool pool = sch.use_pool && sch.next_item && sch.n_cus && (stack_depth <= PT_PP_STACK || sch.pool_gstack) && p.width <= 0xFFFFu &&
                       p.height <= 0xFFFFu && p.depth >= 1u;  // it packs pixel coordinates into 16 bits each and gives every new path a ray
-    const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost ||
-                        (overflow && !pool);
-    if (overflow && !pool && (!p.gstack || p.gstack_cap < stack_depth)) return hipErrorInvalidValue;
+    const bool direct = p.n_frames < sch.min_planned_frames || !sch.items || !sch.partial || !sch.tile_items || !sch.sorted || !sch.cost;
+    // the per-tile kernel's spill buffer has one column per lane of the launch's largest grid
+    const bool spills = overflow && !pool;
+    if (spills && (!p.gstack || p.gstack_cap < stack_depth || p.gstack_blocks < p.n_tiles)) return hipErrorInvalidValue;
     if (direct) {
         p.items = nullptr;
         p.partial = nullptr;
@@ -1769,7 +1768,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
         if (p.n_frames == 0) return hipSuccess;
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
-    if (cap > sch.item_cap) return hipErrorInvalidValue;
+    if (cap > sch.item_cap || (spills && p.gstack_blocks < cap)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk, sch.min_chunk,
                        sch.items, cap, sch.tile_items, sch.sorted);
     if ((e = hipGetLastError()) != hipSuccess) return e;

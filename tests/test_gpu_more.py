@@ -73,7 +73,7 @@ def test_all_materials_and_spp_gt_1(pt, po, scenes):
     r.close()
 
 
-def test_deep_tree_spills_past_lds_stack(pt, po, scenes, megakernel):
+def test_deep_tree_spills_past_lds_stack(pt, po, scenes):
     """Sheets stacked ever closer to z = 0 give the midpoint builder a chain (each split peels off
     the farthest sheet); a ray towards them enters the near child and pushes the far one at every
     level, so the stack grows to the depth of the tree -- far past its LDS part."""
@@ -98,19 +98,16 @@ def test_deep_tree_spills_past_lds_stack(pt, po, scenes, megakernel):
     gprim, gt = r.read_aov()
     assert np.array_equal(gprim, prim) and (prim < 0x80000000).sum() > 20
     _exact(r.read_sum(), acc, "radiance")
-    # many frames in one call: the per-tile kernel keeps spilling trees on its one-item-per-tile path
-    # (sequential sums); the pooled kernel plans work items, so its sums differ by summation order
+    # many frames in one call: planned work items with spilling stacks; sums differ from the
+    # frame-by-frame ones by summation order only
     r.reset_ready_samples()
     r.render_frames(1, 1, 20)
     acc = np.zeros((64, 96, 4), np.float32)
     for t in range(1, 21):
         osc.render(t, acc)
-    if megakernel == "tile":
-        _exact(r.read_sum(), acc, "radiance, 20 frames in one call")
-    else:
-        got = r.read_sum()
-        assert np.array_equal(got[..., 3], acc[..., 3])
-        np.testing.assert_allclose(got, acc, rtol=20 * 2.0 ** -23, atol=1e-6)
+    got = r.read_sum()
+    assert np.array_equal(got[..., 3], acc[..., 3])
+    np.testing.assert_allclose(got, acc, rtol=20 * 2.0 ** -23, atol=1e-6)
     r.close()
 
 
