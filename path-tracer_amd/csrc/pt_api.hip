@@ -493,10 +493,12 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
     // global memory) and wins when BVH walks are long, i.e. on big meshes; measured on this GPU
     // (tools/kernel_choice.py) the per-tile kernel is faster up to ~12k triangles and the pooled one from
-    // ~70k on (3.7x at 10 M), so the switch is the triangle count.  Flags or PTRT_KERNEL force either;
+    // ~70k on, provided the launch is long enough to fill its path pool (69k triangles: 9.9 vs 18.1 Grays/s
+    // at 32 frames, 25.4 vs 25.4 at 128, 30.0 vs 28.4 at 256), so the switch is triangle count and
+    // launch length.  Flags or PTRT_KERNEL force either;
     // depth 0 and images wider or taller than 65535 always take the per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
-    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES;
+    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && n_frames >= PT_POOL_MIN_FRAMES;
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags

@@ -107,3 +107,7 @@ def test_automatic_choice_by_mesh_size(pt, scenes):
         auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 6)])
         forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_TILE_KERNEL, [(1, 1, 6)])
         assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]
+    # a long launch on the big mesh goes to the pooled kernel: same bits as with that kernel forced
+    auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 130)])
+    forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_POOL_KERNEL, [(1, 1, 130)])
+    assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]
