@@ -521,6 +521,32 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// The kernel's parameter block is large (scene pointers, camera frame, the root's child boxes).  Kept
+// in scalar registers for the whole persistent loop it overflows them, and every spilled value costs
+// vector instructions in the walk loop.  The shading pass and the job hand-out therefore re-read the
+// block from the kernel-argument segment (scalar loads, live only while they run); the asm statement
+// keeps the compiler from hoisting those loads back out of the loop.
+typedef const __attribute__((address_space(4))) uint32_t *PtKernargWords;
+static_assert(sizeof(PtTraceParams) % 4 == 0, "parameter block is read word by word");
+__device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
+{
+    PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();  // the block is the kernel's only argument
+    asm volatile("" : "+s"(kw));
+    uint32_t *lw = reinterpret_cast<uint32_t *>(&L);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
+}
+// The pointers are taken from the kernel argument itself: the compiler knows that those point to
+// global memory, while a pointer rebuilt from plain words would be dereferenced through the slower
+// generic-address path.
+#define PT_FRESH_PARAMS(L)                                                                                       \
+    PtTraceParams L;                                                                                             \
+    pt_fresh_params(L);                                                                                          \
+    L.sc.spheres = P.sc.spheres; L.sc.nodes = P.sc.nodes; L.sc.node_meta = P.sc.node_meta;                      \
+    L.sc.tri_pos = P.sc.tri_pos; L.sc.tri_nrm = P.sc.tri_nrm; L.sc.sky = P.sc.sky;                              \
+    L.items = P.items; L.partial = P.partial; L.cost = P.cost; L.accum = P.accum;                               \
+    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t; L.next_item = P.next_item
+
 // ---- the megakernel ---------------------------------------------------------------------
 // GIZMO: some sphere has material 3 (only then is the path's first direction kept);
 // SPP1: one sample per pixel and dispatch (the per-frame sample sum is the sample itself);
@@ -595,7 +621,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 
     // Retire finished paths and start new ones until this lane holds a ray to trace (or is done).
     // path_done/result describe the path that just ended (ignored when need_new is set).
-    auto advance = [&](bool path_done, v3 result) {
+    auto advance = [&](const PtTraceParams &Q, bool path_done, v3 result) {
         while (active && (need_new || path_done || bounce >= limit)) {
             if (!need_new) {
                 // rayColor returned: compute.wgsl:121
@@ -605,9 +631,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
                     frame_sum = frame_sum + path_color;
                     sample++;
                 }
-                if (SPP1 || sample == P.spp) {
+                if (SPP1 || sample == Q.spp) {
                     // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
-                    const v3 mean = (SPP1 ? path_color : frame_sum) * P.inv_spp;
+                    const v3 mean = (SPP1 ? path_color : frame_sum) * Q.inv_spp;
                     float4 acc = lds_acc[lane];
                     acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
                     lds_acc[lane] = acc;
@@ -619,23 +645,23 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
             }
             if (sample == 0) {
                 // compute.wgsl:85
-                const uint32_t time = P.time0 + frame * P.stride;
+                const uint32_t time = Q.time0 + frame * Q.stride;
                 sx = x; sy = y; sz = x + time; sw = y + time;
             }
             // compute.wgsl:113-119, 131-136
             const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
             const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-            const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
-            const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));  // compute.wgsl:109
-            cur.o = P.fr.origin;
-            cur.d = (ploc + smp) - P.fr.origin;
+            const v3 smp = v3_fma(py, Q.fr.dv, Q.fr.du * px);
+            const v3 ploc = v3_fma((float)y, Q.fr.dv, v3_fma((float)x, Q.fr.du, Q.fr.pixel00));  // compute.wgsl:109
+            cur.o = Q.fr.origin;
+            cur.d = (ploc + smp) - Q.fr.origin;
             if (GIZMO) initial_d = cur.d;
             color = V3(1.0f, 1.0f, 1.0f);
             seed = pt_hybrid_taus(sx, sy, sz, sw);
             bounce = 0;
-            limit = P.depth;
+            limit = Q.depth;
             need_new = false;
-            want_aov = (frame == 0 && sample == 0 && P.aov_prim != nullptr);
+            want_aov = (frame == 0 && sample == 0 && Q.aov_prim != nullptr);
         }
     };
 
@@ -666,28 +692,25 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
             diag_iters++;
             diag_s = clock64();
 #endif
+            // (the shading block re-reads the parameter block, so that the walk loop does not have to keep
+            // all of it in scalar registers)
+            PT_FRESH_PARAMS(L);
             if (mode == M_SHADE) {
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 if (!need_new) {
                     uint32_t prim;
-#ifdef PT_DEBUG_PIXEL
-                    if (x == 27 && y == 20) printf("C pre  b=%u o=%a %a %a d=%a %a %a hit=%d idx=%u t=%a seed=%a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)w.rec.hit, w.rec.index, w.rec.t, seed);
-#endif
-                    path_done = shade_ray<STATS, GIZMO>(sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
-#ifdef PT_DEBUG_PIXEL
-                    if (x == 27 && y == 20) printf("C post b=%u o=%a %a %a d=%a %a %a done=%d col=%a %a %a\n", bounce, cur.o.x, cur.o.y, cur.o.z, cur.d.x, cur.d.y, cur.d.z, (int)path_done, color.x, color.y, color.z);
-#endif
+                    path_done = shade_ray<STATS, GIZMO>(L.sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
                     if (want_aov) {
-                        P.aov_prim[pix] = prim;
-                        P.aov_t[pix] = w.rec.hit ? w.rec.t : 0.0f;
+                        L.aov_prim[pix] = prim;
+                        L.aov_t[pix] = w.rec.hit ? w.rec.t : 0.0f;
                         want_aov = false;
                     }
                 }
-                advance(path_done, result);
+                advance(L, path_done, result);
                 if (active) {
                     cn.rays++;
-                    mode = walk_begin<STATS>(sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
+                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
                     if (mode == M_WALK) walk_enter(w);
                 } else {
@@ -942,32 +965,6 @@ __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uin
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return id;
 }
-
-// The kernel's parameter block is large (scene pointers, camera frame, the root's child boxes).  Kept
-// in scalar registers for the whole persistent loop it overflows them, and every spilled value costs
-// vector instructions in the walk loop.  The shading pass and the job hand-out therefore re-read the
-// block from the kernel-argument segment (scalar loads, live only while they run); the asm statement
-// keeps the compiler from hoisting those loads back out of the loop.
-typedef const __attribute__((address_space(4))) uint32_t *PtKernargWords;
-static_assert(sizeof(PtTraceParams) % 4 == 0, "parameter block is read word by word");
-__device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
-{
-    PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();  // the block is the kernel's only argument
-    asm volatile("" : "+s"(kw));
-    uint32_t *lw = reinterpret_cast<uint32_t *>(&L);
-#pragma unroll
-    for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
-}
-// The pointers are taken from the kernel argument itself: the compiler knows that those point to
-// global memory, while a pointer rebuilt from plain words would be dereferenced through the slower
-// generic-address path.
-#define PT_FRESH_PARAMS(L)                                                                                       \
-    PtTraceParams L;                                                                                             \
-    pt_fresh_params(L);                                                                                          \
-    L.sc.spheres = P.sc.spheres; L.sc.nodes = P.sc.nodes; L.sc.node_meta = P.sc.node_meta;                      \
-    L.sc.tri_pos = P.sc.tri_pos; L.sc.tri_nrm = P.sc.tri_nrm; L.sc.sky = P.sc.sky;                              \
-    L.items = P.items; L.partial = P.partial; L.cost = P.cost; L.accum = P.accum;                               \
-    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t; L.next_item = P.next_item
 
 template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
