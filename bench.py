@@ -186,10 +186,12 @@ def main():
                        "parallelism": f"sample-split x{world}, one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "pool_kernel (+ plan_kernel, accumulate_kernel, and a 4-frame probe launch in the first step)",
+                         "kernel": "pool_kernel for this workload (library default for meshes >= 32768 triangles and launches >= 128 "
+                                   "frames; trace_kernel otherwise), + plan_kernel, accumulate_kernel, and a 4-frame probe launch in the first step",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_GBps": abytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+                         "hbm_traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "note": "VALU-bound traversal: no MFMA (nothing is a dense contraction); working set "
                                  "is L2/Infinity-Cache resident, so the HBM figure is informational"},
         }
