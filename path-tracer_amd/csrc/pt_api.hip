@@ -3,9 +3,11 @@
 // Device data layout (all hipMalloc, lives for the context):
 //   accum     width*height float4   running RGB sums, .w = frame count
 //   spheres   3 float4 per sphere   {center, radius} {albedo, material} {1/radius, 0, 0, 0}
-//   nodes     2 float4 per node     {min, token} {max, count}; the array is stored one node
-//                                   late so that every sibling pair (odd, even index) is one
-//                                   64-byte aligned block
+//   nodes     4 float4 per sibling  {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
+//             pair (l, l+1)         {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}: the pair interleaved
+//                                   component by component (two-wide slab tests), at the place of nodes l
+//                                   and l+1; the array is stored one node late so that every pair
+//                                   (odd, even index) is one 64-byte aligned block
 //   node_meta uint2 per node        (first, count), read only for leaves with > 7 triangles
 //   tri_pos   3 float4 per slot     {a, original index} {b-a} {c-a}, slot = position in the
 //                                   BVH's index permutation, so a leaf's triangles are contiguous
@@ -308,8 +310,10 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
         if (n.triangle_count == 0) {
             const uint64_t l = n.left_child_index;
             if (l <= i || l + 1 >= n_nodes) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: node %u has children %llu,%llu outside (%u, %u)", i, (unsigned long long)l, (unsigned long long)l + 1, i, n_nodes);
-            depth[l] = std::max(depth[l], depth[i] + 1);
-            depth[l + 1] = std::max(depth[l + 1], depth[i] + 1);
+            // the device layout stores sibling pairs interleaved in place, so a node can have one parent only
+            if (depth[l] >= 0 || depth[l + 1] >= 0) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: node %llu or %llu has more than one parent (not a tree)", (unsigned long long)l, (unsigned long long)l + 1);
+            depth[l] = depth[i] + 1;
+            depth[l + 1] = depth[i] + 1;
         } else {
             const uint64_t end = (uint64_t)n.left_child_index + n.triangle_count;
             if (end > n_idx) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: leaf %u covers indices [%u, %llu) beyond %u", i, n.left_child_index, (unsigned long long)end, n_idx);
@@ -325,14 +329,21 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
         return PT_TOKEN_LEAF | i;
     };
 
-    std::vector<float4> h_nodes(2 * ((size_t)n_nodes + 1));
+    // Sibling pairs (l, l+1), interleaved component by component so that the two slab tests of a node
+    // visit are packed two-wide: {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
+    // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}, at the place of nodes l and l+1.
+    std::vector<float4> h_nodes(2 * ((size_t)n_nodes + 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     std::vector<uint2> h_meta(n_nodes);
-    h_nodes[0] = h_nodes[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < n_nodes; i++) {
         const PtNode &n = nodes[i];
-        h_nodes[2 * ((size_t)i + 1)] = make_float4(n.min_corner[0], n.min_corner[1], n.min_corner[2], u2f(token_of(i)));
-        h_nodes[2 * ((size_t)i + 1) + 1] = make_float4(n.max_corner[0], n.max_corner[1], n.max_corner[2], u2f(n.triangle_count));
         h_meta[i] = make_uint2(n.left_child_index, n.triangle_count);
+        if (depth[i] < 0 || n.triangle_count != 0) continue;
+        const PtNode &a = nodes[n.left_child_index], &b = nodes[n.left_child_index + 1];
+        float4 *rec = &h_nodes[2 * ((size_t)n.left_child_index + 1)];
+        rec[0] = make_float4(a.min_corner[0], b.min_corner[0], a.min_corner[1], b.min_corner[1]);
+        rec[1] = make_float4(a.min_corner[2], b.min_corner[2], a.max_corner[0], b.max_corner[0]);
+        rec[2] = make_float4(a.max_corner[1], b.max_corner[1], a.max_corner[2], b.max_corner[2]);
+        rec[3] = make_float4(u2f(token_of(n.left_child_index)), u2f(token_of(n.left_child_index + 1)), 0.0f, 0.0f);
     }
     // one float4 of padding: the step-wise walk reads four float4 from a triangle's address
     std::vector<float4> h_pos(3 * (size_t)n_idx + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);

@@ -73,14 +73,21 @@ struct HitRecord {
     uint32_t prim;
 };
 
-// hitAabb, compute.wgsl:441-456, with 1/direction hoisted out (same correctly rounded value).
-__device__ __forceinline__ float hit_aabb(v3 o, v3 inv, float4 lo, float4 hi)
+// hitAabb, compute.wgsl:441-456, with 1/direction hoisted out (same correctly rounded value), for the
+// two children of a node at once.  q0..q2 hold the pair interleaved {l, r} per component (see the node
+// layout in pt_api.hip), so the subtractions and multiplications are two-wide packed instructions;
+// per child they are the same operations in the same order as the one-box form.
+typedef float pt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hit_aabb_pair(v3 o, v3 inv, float4 q0, float4 q1, float4 q2, float &dl, float &dr)
 {
-    const v3 t1 = (f4_xyz(lo) - o) * inv;
-    const v3 t2 = (f4_xyz(hi) - o) * inv;
-    const float tmin = pt_max(pt_max(pt_min(t1.x, t2.x), pt_min(t1.y, t2.y)), pt_min(t1.z, t2.z));
-    const float tmax = pt_min(pt_min(pt_max(t1.x, t2.x), pt_max(t1.y, t2.y)), pt_max(t1.z, t2.z));
-    return (tmin > tmax || tmax < 0.0f) ? 99999.0f : tmin;
+    const pt_f2 t1x = (pt_f2{q0.x, q0.y} - o.x) * inv.x, t1y = (pt_f2{q0.z, q0.w} - o.y) * inv.y, t1z = (pt_f2{q1.x, q1.y} - o.z) * inv.z;
+    const pt_f2 t2x = (pt_f2{q1.z, q1.w} - o.x) * inv.x, t2y = (pt_f2{q2.x, q2.y} - o.y) * inv.y, t2z = (pt_f2{q2.z, q2.w} - o.z) * inv.z;
+    const float tmin_l = pt_max(pt_max(pt_min(t1x.x, t2x.x), pt_min(t1y.x, t2y.x)), pt_min(t1z.x, t2z.x));
+    const float tmax_l = pt_min(pt_min(pt_max(t1x.x, t2x.x), pt_max(t1y.x, t2y.x)), pt_max(t1z.x, t2z.x));
+    const float tmin_r = pt_max(pt_max(pt_min(t1x.y, t2x.y), pt_min(t1y.y, t2y.y)), pt_min(t1z.y, t2z.y));
+    const float tmax_r = pt_min(pt_min(pt_max(t1x.y, t2x.y), pt_max(t1y.y, t2y.y)), pt_max(t1z.y, t2z.y));
+    dl = (tmin_l > tmax_l || tmax_l < 0.0f) ? 99999.0f : tmin_l;
+    dr = (tmin_r > tmax_r || tmax_r < 0.0f) ? 99999.0f : tmin_r;
 }
 
 // hitScene, compute.wgsl:214-302, split into "begin" (spheres in array order, traversal set-up)
@@ -150,9 +157,9 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     // First visit (the root's two children) from wave-uniform registers instead of memory: most
     // rays of an outdoor scene end their walk right here.
     if (STATS) cn.interior++;
-    float d1 = hit_aabb(o, w.inv, sc.root_pair[0], sc.root_pair[1]);
-    float d2 = hit_aabb(o, w.inv, sc.root_pair[2], sc.root_pair[3]);
-    uint32_t k1 = __float_as_uint(sc.root_pair[0].w), k2 = __float_as_uint(sc.root_pair[2].w);
+    float d1, d2;
+    hit_aabb_pair(o, w.inv, sc.root_pair[0], sc.root_pair[1], sc.root_pair[2], d1, d2);
+    uint32_t k1 = __float_as_uint(sc.root_pair[3].x), k2 = __float_as_uint(sc.root_pair[3].y);
     if (d1 > d2) {
         const float td = d1; d1 = d2; d2 = td;
         const uint32_t tk = k1; k1 = k2; k2 = tk;
@@ -172,10 +179,10 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     if (!(cur & PT_TOKEN_LEAF)) {
         if (STATS) cn.interior++;
         const float4 *pn = sc.nodes + 2 * (size_t)cur;  // children cur, cur+1: 64 contiguous bytes
-        const float4 l0 = pn[0], l1 = pn[1], r0 = pn[2], r1 = pn[3];
-        float d1 = hit_aabb(o, w.inv, l0, l1);
-        float d2 = hit_aabb(o, w.inv, r0, r1);
-        uint32_t k1 = __float_as_uint(l0.w), k2 = __float_as_uint(r0.w);
+        const float4 q0 = pn[0], q1 = pn[1], q2 = pn[2], q3 = pn[3];
+        float d1, d2;
+        hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
+        uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
         if (d1 > d2) {
             const float td = d1; d1 = d2; d2 = td;
             const uint32_t tk = k1; k1 = k2; k2 = tk;
@@ -268,12 +275,12 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
-        asm volatile("" : "+v"(q0.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z));
+        asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y));
         if (!tri) {
             if (STATS) cn.interior++;
-            float d1 = hit_aabb(o, w.inv, q0, q1);
-            float d2 = hit_aabb(o, w.inv, q2, q3);
-            uint32_t k1 = __float_as_uint(q0.w), k2 = __float_as_uint(q2.w);
+            float d1, d2;
+            hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
+            uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
             if (d1 > d2) {
                 const float td = d1; d1 = d2; d2 = td;
                 const uint32_t tk = k1; k1 = k2; k2 = tk;
