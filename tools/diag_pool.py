@@ -10,6 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _pkgload
 
+os.environ.setdefault("PTRT_KERNEL", "pool")  # these counters exist in the pooled kernel only
 pt = _pkgload.load()
 scenes = importlib.import_module("path_tracer_amd.scenes")
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
