@@ -204,12 +204,12 @@ def test_malformed_bvh_is_rejected(pt, scenes):
     bad["count"][leaf] = 1000               # leaf range past the index array
     with pytest.raises(pt.PtError):
         r.set_mesh(scene.triangles, bad, scene.triangle_indices)
-    interior = np.nonzero(nodes["count"] == 0)[0]
-    if len(interior) >= 2:
-        bad = nodes.copy()
-        bad["left"][interior[0]] = nodes["left"][interior[1]]   # two parents share a pair of children: not a tree
-        with pytest.raises(pt.PtError):
-            r.set_mesh(scene.triangles, bad, scene.triangle_indices)
+    assert nodes["count"][1] == 0 and nodes["count"][2] != 0, "test assumes node 1 interior, node 2 leaf"
+    bad = nodes.copy()
+    bad["count"][2] = 0
+    bad["left"][2] = nodes["left"][1]       # nodes 1 and 2 share a pair of children: not a tree
+    with pytest.raises(pt.PtError):
+        r.set_mesh(scene.triangles, bad, scene.triangle_indices)
     idx = scene.triangle_indices.copy()
     idx[0] = 99                             # triangle index out of range
     with pytest.raises(pt.PtError):
