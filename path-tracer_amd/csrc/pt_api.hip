@@ -563,6 +563,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     if (const char *env = getenv("PTRT_POOL_DENSE")) p.pool_dense = (uint32_t)atoi(env);  // tuning aid
     p.pool_shade_dense = 128;
     if (const char *env = getenv("PTRT_POOL_SHADE_DENSE")) p.pool_shade_dense = (uint32_t)atoi(env);  // tuning aid
+    p.pool_miss_iters = 16;
+    if (const char *env = getenv("PTRT_POOL_MISS_ITERS")) p.pool_miss_iters = (uint32_t)atoi(env);  // tuning aid
+    p.pool_miss_lanes = 48;
+    if (const char *env = getenv("PTRT_POOL_MISS_LANES")) p.pool_miss_lanes = (uint32_t)atoi(env);  // tuning aid
     p.pool_steps = 8;
     if (const char *env = getenv("PTRT_POOL_STEPS")) p.pool_steps = (uint32_t)atoi(env);  // tuning aid
     p.max_idle = 1u << 22;

@@ -66,6 +66,8 @@ struct PtTraceParams {
     uint32_t pool_dense;           // walkers that make a wave "walking" in that sense
     uint32_t pool_shade_dense;     // ready paths at which even a walking wave runs a shading pass
     uint32_t pool_steps;           // node visits per loop trip
+    uint32_t pool_miss_iters;      // most rounds a pass over misses keeps its slots in registers (1: none)
+    uint32_t pool_miss_lanes;      // ... as long as this many lanes still carry a slot
     uint32_t max_idle;             // consecutive idle trips after which a wave gives up
 };
 

@@ -1400,7 +1400,154 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     }
                 }
             };
+            // A pass over misses keeps going in registers: a pixel whose ray missed everything usually sends
+            // its next primary ray into the sky too, so the lane shades that one as well instead of sending the
+            // slot through LDS and the ring again; lanes leave the loop when their new ray hits something or
+            // needs a walk (state to LDS, slot to the matching ring) or when their job ends, and the loop ends
+            // when too few lanes are left or after pool_miss_iters rounds.
+            auto miss_pass = [&]() {
+                p = ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+                bool mine = p != 0xFFFFFFFFu;  // this lane still carries its slot through the loop
+                uint32_t x = 0, y = 0, frame_end = 0, pidx = 0, frame = 0, sample = 0, cost = 0;
+                bool have_ray = false, want_aov = false, dirty = false;
+                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                v3 d = V3(0.0f, 0.0f, 0.0f), color = V3(1.0f, 1.0f, 1.0f), fsum = V3(0.0f, 0.0f, 0.0f);
+                uint32_t rx = 0, ry = 0, rz = 0, rw = 0;  // HybridTaus state between the samples of a frame (spp > 1)
+                if (mine) {
+                    const uint32_t xy = sh.st[F_XY][p];
+                    x = xy & 0xFFFFu;
+                    y = xy >> 16;
+                    frame_end = sh.st[F_FEND][p];
+                    pidx = sh.st[F_PIDX][p];
+                    acc = sums[pidx];
+                    const uint32_t fs = sh.st[F_FS][p];
+                    have_ray = (fs & 1u) != 0;
+                    want_aov = (fs & 2u) != 0;
+                    sample = fs >> 2;
+                    frame = sh.st[F_FRAME][p];
+                    cost = sh.st[F_COST][p];
+                    if (have_ray) {
+                        d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
+                        color = V3(__uint_as_float(sh.st[F_COLR][p]), __uint_as_float(sh.st[F_COLG][p]), __uint_as_float(sh.st[F_COLB][p]));
+                    }
+                    if constexpr (!SPP1) {
+                        fsum = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p]));
+                        rx = sh.st[FL::RNG][p]; ry = sh.st[FL::RNG + 1][p]; rz = sh.st[FL::RNG + 2][p]; rw = sh.st[FL::RNG + 3][p];  // (unused by a frame's first sample)
+                    }
+                }
+                for (uint32_t round = 0;; round++) {
+                    if (mine) {
+                        // the ray in hand missed everything: compute.wgsl:140-143
+                        v3 sky = V3(1.0f, 1.0f, 1.0f), path_color = color;
+                        const bool retire = have_ray;
+                        bool frame_ends = false;
+                        if (retire) {
+                            if (STATS) cn.sky++;
+                            sky = sky_lookup(sc, d);  // issued here, consumed after the next ray is set up
+                            if (want_aov) {
+                                L.aov_prim[(size_t)y * L.width + x] = 0xFFFFFFFFu;
+                                L.aov_t[(size_t)y * L.width + x] = 0.0f;
+                                want_aov = false;
+                            }
+                            // frame and sample counters of the retiring path (compute.wgsl:112-128)
+                            if constexpr (!SPP1) sample++;
+                            if (SPP1 || sample == L.spp) {
+                                frame_ends = true;
+                                sample = 0;
+                                frame++;
+                            }
+                        }
+                        cost += 8u;  // a shading round weighs like eight node visits
+                        if (frame == frame_end) {
+                            finished = true;
+                            mine = false;
+                            if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                        } else {
+                            // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
+                            uint32_t sx = x, sy = y, sz = x + (L.time0 + frame * L.stride), sw = y + (L.time0 + frame * L.stride);  // compute.wgsl:85
+                            if constexpr (!SPP1) {
+                                if (sample != 0) { sx = rx; sy = ry; sz = rz; sw = rw; }
+                            }
+                            const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                            const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                            const v3 smp = v3_fma(py, L.fr.dv, L.fr.du * px);
+                            const v3 ploc = v3_fma((float)y, L.fr.dv, v3_fma((float)x, L.fr.du, L.fr.pixel00));  // compute.wgsl:109
+                            Ray cur;
+                            cur.o = L.fr.origin;
+                            cur.d = (ploc + smp) - L.fr.origin;
+                            const float seed = pt_hybrid_taus(sx, sy, sz, sw);
+                            if constexpr (!SPP1) { rx = sx; ry = sy; rz = sz; rw = sw; }
+                            want_aov = (frame == 0 && sample == 0 && L.aov_prim != nullptr);
+                            cn.rays++;
+                            Walk nw;
+                            uint32_t k2 = 0xFFFFFFFFu;
+                            const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
+                            if (need_walk || nw.rec.hit) {
+                                // this ray goes on elsewhere: the slot's whole state to LDS
+                                sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
+                                sh.st[F_DX][p] = __float_as_uint(cur.d.x); sh.st[F_DY][p] = __float_as_uint(cur.d.y); sh.st[F_DZ][p] = __float_as_uint(cur.d.z);
+                                sh.st[F_T][p] = __float_as_uint(nw.rec.t);
+                                sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
+                                sh.st[F_U][p] = need_walk ? nw.node : 0u;
+                                sh.st[F_V][p] = need_walk ? k2 : 0u;
+                                sh.st[F_COLR][p] = __float_as_uint(1.0f); sh.st[F_COLG][p] = __float_as_uint(1.0f); sh.st[F_COLB][p] = __float_as_uint(1.0f);
+                                sh.st[F_SEED][p] = __float_as_uint(seed);
+                                sh.st[F_BOUNCE][p] = 0u;
+                                sh.st[F_FRAME][p] = frame;
+                                sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
+                                sh.st[F_COST][p] = cost;
+                                if constexpr (GIZMO) {
+                                    sh.st[FL::IDIR][p] = __float_as_uint(cur.d.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(cur.d.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(cur.d.z);
+                                    sh.st[FL::LIMIT][p] = L.depth;
+                                }
+                                if constexpr (!SPP1) { sh.st[FL::RNG][p] = rx; sh.st[FL::RNG + 1][p] = ry; sh.st[FL::RNG + 2][p] = rz; sh.st[FL::RNG + 3][p] = rw; }
+                                to_pending = need_walk;
+                                to_hit = !need_walk;
+                                mine = false;
+                            } else {
+                                // another miss: stays in this lane's registers
+                                d = cur.d;
+                                color = V3(1.0f, 1.0f, 1.0f);
+                                have_ray = true;
+                            }
+                        }
+                        // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
+                        if (retire) {
+                            path_color = path_color * sky;
+                            if constexpr (!SPP1) path_color = fsum + path_color;
+                            if (frame_ends) {
+                                // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                                const v3 mean = path_color * L.inv_spp;
+                                acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                                dirty = true;
+                                path_color = V3(0.0f, 0.0f, 0.0f);
+                            }
+                            if constexpr (!SPP1) fsum = path_color;
+                        }
+                    }
+                    const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine));
+                    if (n_mine < L.pool_miss_lanes || round + 1u >= L.pool_miss_iters) break;
+                }
+                if (p != 0xFFFFFFFFu) {
+                    if (dirty) sums[pidx] = acc;
+                    if constexpr (!SPP1) {
+                        // (a lane that left with a hit or a walk stored its RNG state above; the sample sum is common)
+                        sh.st[FL::FSUM][p] = __float_as_uint(fsum.x); sh.st[FL::FSUM + 1][p] = __float_as_uint(fsum.y); sh.st[FL::FSUM + 2][p] = __float_as_uint(fsum.z);
+                    }
+                    if (mine) {
+                        // still holding a missed ray when the loop ended: what the next pass over misses reads
+                        sh.st[F_DX][p] = __float_as_uint(d.x); sh.st[F_DY][p] = __float_as_uint(d.y); sh.st[F_DZ][p] = __float_as_uint(d.z);
+                        sh.st[F_COLR][p] = __float_as_uint(color.x); sh.st[F_COLG][p] = __float_as_uint(color.y); sh.st[F_COLB][p] = __float_as_uint(color.z);
+                        sh.st[F_FRAME][p] = frame;
+                        sh.st[F_FS][p] = (have_ray ? 1u : 0u) | (want_aov ? 2u : 0u) | (sample << 2);
+                        sh.st[F_COST][p] = cost;
+                        if constexpr (!SPP1) { sh.st[FL::RNG][p] = rx; sh.st[FL::RNG + 1][p] = ry; sh.st[FL::RNG + 2][p] = rz; sh.st[FL::RNG + 3][p] = rw; }
+                        to_ready = true;
+                    }
+                }
+            };
             if (pass_hits) shading_pass(std::true_type{});
+            else if (L.pool_miss_iters > 1u) miss_pass();
             else shading_pass(std::false_type{});
 #ifdef PT_DIAG
             if (!pass_hits) { const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
