@@ -22,6 +22,7 @@
 #ifndef PTRT_H
 #define PTRT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -121,6 +122,19 @@ int pt_read_sum_rgba32f(pt_ctx *ctx, float *out);
 int pt_read_mean_rgba32f(pt_ctx *ctx, float *out);
 /* Mean clamped to [0,1] and quantised like an rgba8unorm store (compute.wgsl:72,127). */
 int pt_read_rgba8(pt_ctx *ctx, uint8_t *out);
+/* ProgressiveRendering (renderer.rs:613-646) + copy.wgsl:27-37, for callers that want the picture the
+ * reference puts on screen: with sample_size in 1..256 (MAX_NUMBER_OF_SAMPLES, renderer.rs:11) every frame
+ * is also kept as an rgba8unorm texel image (the shader's store, compute.wgsl:124-127) in a ring of
+ * sample_size frames, rendering proceeds one launch per frame, and ready_samples is tracked as
+ * Renderer::render does (starts at 0; pt_reset sets it to 1 like reset_ready_samples).  0 turns it off
+ * (default).  The fp32 sums are kept as without a window.  Not combinable with pt_bind_accum. */
+int pt_set_window(pt_ctx *ctx, uint32_t sample_size);
+/* What the last rendered frame's copy pass shows: the mean of the newest
+ * n = min(sample_size, ready_samples before that frame) texel images, summed newest first in f32 and
+ * divided by n (copy.wgsl:27-37); rgba8_out quantises that once more like a linear 8-bit surface.
+ * Either output may be NULL; *frames_shown (may be NULL) receives n.  n == 0 (the very first frame
+ * of a context, where the reference divides 0 by 0) is PT_ERR_STATE when an image is asked for. */
+int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown);
 /* Primary-hit primitive id and t per pixel (needs PT_FLAG_AOV during rendering). */
 int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t);
 int pt_stats(pt_ctx *ctx, pt_stats_t *out);
@@ -151,6 +165,12 @@ int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data8208_out
  * 112-byte records.  Faces are fan-triangulated; vertices without `vn` get area-weighted
  * smooth normals (the reference would panic on a file without normals). */
 int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris);
+/* Radiance .hdr bytes -> w x h RGBA32F panorama, as CubeTexture::from_equirectangular_hdri
+ * decodes its `data` argument (src/texture.rs:179-188: HdrDecoder + Rgbe8Pixel::to_hdr, alpha 1);
+ * the result is what pt_set_sky_equirect takes.  First call with rgba_out == NULL for the
+ * size, then with room for capacity_pixels >= w*h pixels. */
+int pt_hdr_decode(const void *data, size_t n_bytes, float *rgba_out, size_t capacity_pixels,
+                  uint32_t *width, uint32_t *height);
 /* Message of the last failed host-side helper on this thread. */
 const char *pt_host_error(void);
 

@@ -183,3 +183,131 @@ def equirect_to_cube(pano, size):
     out = np.zeros((6, size, size, 4), np.float32)
     lib().pto_equirect_to_cube(_p(pano), pano.shape[1], pano.shape[0], _p(out), size)
     return out
+
+
+def hdr_decode(data: bytes) -> np.ndarray:
+    """Radiance .hdr bytes -> (h, w, 4) float32, restating what src/texture.rs:179-188 gets from image 0.24.7
+    (a crate outside the reference tree; no reference fixture exercises it: parity unpinned): strict
+    HdrDecoder (signature "#?RADIANCE", header up to an empty line, FORMAT=32-bit_rle_rgbe, "-Y h +X w"),
+    scanlines in the per-component run-length coding or the old 1,1,1,n repeat coding, and
+    Rgbe8Pixel::to_hdr = mantissa * 2^(e-136), black for e == 0; alpha 1.  Raises ValueError on bad data."""
+    data = bytes(data)
+    if data[:10] != b"#?RADIANCE":
+        raise ValueError("signature")
+    at = data.find(b"\n", 10)
+    if at < 0:
+        raise ValueError("header")
+    at += 1
+
+    def line():
+        nonlocal at
+        if at >= len(data):
+            raise ValueError("truncated header")
+        end = data.find(b"\n", at)
+        end = len(data) if end < 0 else end
+        out = data[at:end]
+        at = end + 1
+        return out
+
+    while True:
+        ln = line()
+        if not ln:
+            break
+        if ln[:1] == b"#":
+            continue
+        key, sep, val = ln.partition(b"=")
+        if sep and key == b"FORMAT" and val.strip() != b"32-bit_rle_rgbe":
+            raise ValueError("format")
+    parts = line().split()
+    if len(parts) != 4 or parts[0] != b"-Y" or parts[2] != b"+X":
+        raise ValueError("dimensions")
+    if not all(q.lstrip(b"+").isdigit() and q.count(b"+") <= 1 for q in (parts[1], parts[3])):
+        raise ValueError("dimensions")
+    h, w = int(parts[1]), int(parts[3])
+    if w == 0 or h == 0 or w >= 2 ** 32 or h >= 2 ** 32:
+        raise ValueError("dimensions")
+
+    def take(n):
+        nonlocal at
+        if at + n > len(data):
+            raise ValueError("truncated scanline")
+        out = data[at:at + n]
+        at += n
+        return out
+
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    for y in range(h):
+        fb = take(4)
+        if fb[0] == 2 and fb[1] == 2 and fb[2] < 128:
+            for comp in range(4):
+                pos = 0
+                while pos < w:
+                    rl = take(1)[0]
+                    if rl == 0:
+                        raise ValueError("zero-length group")
+                    if rl <= 128:
+                        if pos + rl > w:
+                            raise ValueError("scanline too long")
+                        rgbe[y, pos:pos + rl, comp] = np.frombuffer(take(rl), np.uint8)
+                    else:
+                        rl -= 128
+                        if pos + rl > w:
+                            raise ValueError("scanline too long")
+                        rgbe[y, pos:pos + rl, comp] = take(1)[0]
+                    pos += rl
+        else:
+            if fb[:3] == b"\x01\x01\x01":
+                raise ValueError("first pixel is a run marker")
+            rgbe[y, 0] = np.frombuffer(fb, np.uint8)
+            x, mult, prev = 1, 1, fb
+            while x < w:
+                pix = take(4)
+                if pix[:3] == b"\x01\x01\x01":
+                    rl = pix[3] * mult
+                    mult *= 256
+                    if x + rl > w:
+                        raise ValueError("scanline too long")
+                    rgbe[y, x:x + rl] = np.frombuffer(prev, np.uint8)
+                    x += rl
+                else:
+                    mult, prev = 1, pix
+                    rgbe[y, x] = np.frombuffer(pix, np.uint8)
+                    x += 1
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e == 0, np.float32(0.0), np.ldexp(np.float32(1.0), e - 136).astype(np.float32)).astype(np.float32)
+    out = np.ones((h, w, 4), np.float32)
+    out[..., :3] = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    return out
+
+
+class ProgressiveWindow:
+    """ProgressiveRendering + the copy pass (src/renderer.rs:492-516, 539-541, 560, 613-646; shaders/copy.wgsl:27-37):
+    every frame is an rgba8unorm texture (compute.wgsl:124-127), textures shift down by one before a frame is
+    rendered, and the copy pass shows the f32 mean of the first n of them, n = min(sample_size, ready_samples)
+    taken before ready_samples goes up."""
+
+    def __init__(self, sample_size: int):
+        self.sample_size = sample_size
+        self.ready_samples = 0          # renderer.rs:422
+        self.textures = []              # newest first
+        self.shown = 0
+
+    def reset_ready_samples(self):      # renderer.rs:635-637
+        self.ready_samples = 1
+
+    def frame(self, rgba: np.ndarray):
+        """rgba: the frame's colour, (h, w, 4) float32 with alpha 1 where the dispatch covered the pixel, else zeros."""
+        self.shown = min(self.sample_size, self.ready_samples)
+        self.ready_samples = min(self.ready_samples + 1, self.sample_size)
+        c = np.nan_to_num(rgba.astype(np.float32), nan=0.0)
+        texel = np.rint(np.clip(c, np.float32(0.0), np.float32(1.0)) * np.float32(255.0)).astype(np.uint8)
+        self.textures = [texel] + self.textures[: self.sample_size - 1]
+
+    def displayed(self) -> np.ndarray:
+        if self.shown == 0:
+            raise ValueError("0 textures averaged: the shader divides 0 by 0")
+        color = np.zeros(self.textures[0].shape, np.float32)
+        for i in range(self.shown):     # copy.wgsl:32-34; a texture never written reads as zeros
+            t = self.textures[i] if i < len(self.textures) else np.zeros_like(self.textures[0])
+            color = color + t.astype(np.float32) / np.float32(255.0)
+        return color / np.float32(self.shown)

@@ -84,6 +84,8 @@ ABI = [
     ("pt_read_sum_rgba32f", _I, [_VP, _VP]),
     ("pt_read_mean_rgba32f", _I, [_VP, _VP]),
     ("pt_read_rgba8", _I, [_VP, _VP]),
+    ("pt_set_window", _I, [_VP, _U32]),
+    ("pt_read_window", _I, [_VP, _VP, _VP, C.POINTER(_U32)]),
     ("pt_read_aov", _I, [_VP, _VP, _VP]),
     ("pt_stats", _I, [_VP, C.POINTER(Stats)]),
     ("pt_accum_device_ptr", _VP, [_VP]),
@@ -93,6 +95,7 @@ ABI = [
     ("pt_plane_triangles", _I, [_VP, _VP, _VP, _VP, _U32, _VP]),
     ("pt_pack_spheres", _I, [_VP, _U32, _VP]),
     ("pt_obj_load", _I, [C.c_char_p, _VP, _U32, C.POINTER(_U32)]),
+    ("pt_hdr_decode", _I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(_U32), C.POINTER(_U32)]),
     ("pt_host_error", C.c_char_p, []),
 ]
 
@@ -232,6 +235,17 @@ def load_obj(path: str) -> np.ndarray:
     return out
 
 
+def decode_hdr(data: bytes) -> np.ndarray:
+    """Radiance .hdr bytes -> (h, w, 4) float32 panorama, as CubeTexture::from_equirectangular_hdri decodes
+    its `data` argument (src/texture.rs:179-188); feed it to Renderer.set_sky_equirect."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    _host_check(lib().pt_hdr_decode(_ptr(buf), buf.size, None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 4), np.float32)
+    _host_check(lib().pt_hdr_decode(_ptr(buf), buf.size, _ptr(out), out.shape[0] * out.shape[1], C.byref(w), C.byref(h)))
+    return out
+
+
 @dataclass
 class Scene:
     """Scene::new builds the BVH from the triangle list (src/scene/mod.rs:35-43)."""
@@ -344,6 +358,23 @@ class Renderer:
         out = np.zeros((self.height, self.width, 4), np.uint8)
         self._ck(self._l.pt_read_rgba8(self._ctx, _ptr(out)))
         return out
+
+    def set_window(self, sample_size: int):
+        """ProgressiveRendering.sample_size (renderer.rs:613-646): keep the newest frames as rgba8unorm images; 0 = off."""
+        self._ck(lib().pt_set_window(self._ctx, sample_size))
+
+    def window_frames_shown(self) -> int:
+        n = C.c_uint32(0)
+        self._ck(lib().pt_read_window(self._ctx, None, None, C.byref(n)))
+        return n.value
+
+    def read_window(self):
+        """What copy.wgsl:27-37 shows after the last frame: (mean rgba32f, the same as 8-bit linear, frames averaged)."""
+        mean = np.zeros((self.height, self.width, 4), np.float32)
+        q = np.zeros((self.height, self.width, 4), np.uint8)
+        n = C.c_uint32(0)
+        self._ck(lib().pt_read_window(self._ctx, _ptr(mean), _ptr(q), C.byref(n)))
+        return mean, q, n.value
 
     def read_aov(self):
         prim = np.zeros((self.height, self.width), np.uint32)

@@ -75,6 +75,14 @@ struct pt_ctx {
     size_t scratch_bytes = 0;
 
     uint64_t frames = 0;
+
+    // ProgressiveRendering (renderer.rs:613-646) when pt_set_window has enabled it
+    uint32_t window_size = 0;       // sample_size; 0: off
+    uint32_t ready_samples = 0;     // renderer.rs:422
+    uint32_t window_shown = 0;      // textures the last frame's copy pass averaged
+    uint64_t window_seq = 0;        // frames pushed into the ring so far
+    uint32_t *window_ring = nullptr;  // window_size frames of packed rgba8unorm texels
+    float4 *window_frame = nullptr;   // the frame being rendered (zero between frames)
 };
 
 namespace {
@@ -250,6 +258,8 @@ void pt_destroy(pt_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
+    dev_free(ctx->window_ring);
+    dev_free(ctx->window_frame);
     dev_free(ctx->accum_owned);
     dev_free(ctx->aov_prim);
     dev_free(ctx->aov_t);
@@ -509,7 +519,8 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // launch length.  Flags or PTRT_KERNEL force either;
     // depth 0 and images wider or taller than 65535 always take the per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
-    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && n_frames >= PT_POOL_MIN_FRAMES;
+    const uint32_t launch_frames = ctx->window_size ? 1u : n_frames;  // a display window renders frame by frame
+    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES;
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags
@@ -577,6 +588,41 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     const uint32_t max_frames = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull / per_frame, 1u << 20);
     if (max_frames == 0) return fail(ctx, PT_ERR_LIMIT, "pt_render: spp*depth too large");
 
+    if (ctx->window_size) {
+        // Display emulation: one launch per frame, each frame quantised into the ring like the shader's
+        // rgba8unorm store (compute.wgsl:124-127) and added to the running sums in the same order as usual.
+        const uint32_t n_px = ctx->width * ctx->height;
+        p.n_frames = 1;
+        p.accum = ctx->window_frame;
+        p.gstack_cap = 0;
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->n_tiles, ctx->bvh_depth);
+        if (gs) {
+            int rc = ensure_gstack(ctx, gs);
+            if (rc != PT_OK) return rc;
+            p.gstack_cap = ctx->bvh_depth;
+            p.gstack_blocks = ctx->n_tiles;
+        }
+        p.gstack = ctx->gstack;
+        sch.items = ctx->items;
+        sch.partial = ctx->partial;
+        sch.item_cap = ctx->item_cap;
+        for (uint32_t f = 0; f < n_frames; f++) {
+            // Renderer::render: the copy pass of this frame averages min(sample_size, ready_samples) textures,
+            // counted before increment_ready_samples (renderer.rs:539-541, 560, 623-645)
+            ctx->window_shown = std::min(ctx->window_size, ctx->ready_samples);
+            ctx->ready_samples = std::min(ctx->ready_samples + 1u, ctx->window_size);
+            p.time0 = time0 + f * stride;
+            PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
+            uint32_t *slot = ctx->window_ring + (size_t)(ctx->window_seq % ctx->window_size) * n_px;
+            PT_HIP(ctx, pt_launch_window_push(ctx->window_frame, ctx->accum, slot, n_px, ctx->stream));
+            ctx->window_seq++;
+            ctx->frames++;
+            ctx->paths += (uint64_t)p.cols * p.rows * ctx->settings.samples_per_pixel;
+            p.aov_prim = nullptr;  // the AOV belongs to the first frame of the call
+        }
+        return PT_OK;
+    }
+
     uint32_t done = 0;
     while (done < n_frames) {
         const uint32_t batch = std::min(n_frames - done, max_frames);
@@ -627,6 +673,7 @@ int pt_reset(pt_ctx *ctx)
     PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
     ctx->frames = 0;
     ctx->paths = 0;
+    if (ctx->window_size) ctx->ready_samples = 1;  // reset_ready_samples, renderer.rs:635-637 (the textures keep their contents)
     PT_HIP(ctx, hipMemsetAsync(ctx->next_item + 1, 0, sizeof(uint32_t), ctx->stream));
     return PT_OK;
 }
@@ -685,6 +732,56 @@ int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
     return check_gave_up(ctx);
 }
 
+int pt_set_window(pt_ctx *ctx, uint32_t sample_size)
+{
+    PT_ENTER(ctx);
+    if (sample_size > 256u) return fail(ctx, PT_ERR_LIMIT, "pt_set_window: sample_size %u exceeds MAX_NUMBER_OF_SAMPLES (256)", sample_size);
+    if (ctx->accum != ctx->accum_owned && sample_size) return fail(ctx, PT_ERR_STATE, "pt_set_window: not available while pt_bind_accum is in effect");
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->window_ring);
+    dev_free(ctx->window_frame);
+    ctx->window_size = 0;
+    ctx->ready_samples = 0;
+    ctx->window_shown = 0;
+    ctx->window_seq = 0;
+    if (sample_size == 0) return PT_OK;
+    const size_t n = (size_t)ctx->width * ctx->height;
+    int rc = dev_alloc(ctx, &ctx->window_ring, n * sample_size);
+    if (rc == PT_OK) rc = dev_alloc(ctx, &ctx->window_frame, n);
+    if (rc != PT_OK) {
+        dev_free(ctx->window_ring);
+        dev_free(ctx->window_frame);
+        return rc;
+    }
+    // wgpu textures start zeroed
+    PT_HIP(ctx, hipMemsetAsync(ctx->window_ring, 0, n * sample_size * sizeof(uint32_t), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->window_frame, 0, n * sizeof(float4), ctx->stream));
+    ctx->window_size = sample_size;
+    return PT_OK;
+}
+
+int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown)
+{
+    PT_ENTER(ctx);
+    if (!ctx->window_size) return fail(ctx, PT_ERR_STATE, "pt_read_window: no window (pt_set_window)");
+    if (frames_shown) *frames_shown = ctx->window_shown;
+    if (!rgba32f_out && !rgba8_out) return PT_OK;
+    if (ctx->window_shown == 0)
+        return fail(ctx, PT_ERR_STATE, "pt_read_window: the last frame's copy pass averaged 0 textures (the reference divides 0 by 0 on its first frame)");
+    const uint32_t n = ctx->width * ctx->height;
+    int rc = ensure_scratch(ctx, (size_t)n * (sizeof(float4) + sizeof(uint32_t)));
+    if (rc != PT_OK) return rc;
+    float4 *out_f = static_cast<float4 *>(ctx->scratch);
+    uint32_t *out_u8 = reinterpret_cast<uint32_t *>(out_f + n);
+    const uint32_t newest = (uint32_t)((ctx->window_seq - 1u) % ctx->window_size);
+    PT_HIP(ctx, pt_launch_window_mean(ctx->window_ring, n, ctx->window_size, newest, ctx->window_shown, rgba32f_out ? out_f : nullptr,
+                                      rgba8_out ? out_u8 : nullptr, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rgba32f_out) PT_HIP(ctx, hipMemcpy(rgba32f_out, out_f, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (rgba8_out) PT_HIP(ctx, hipMemcpy(rgba8_out, out_u8, (size_t)n * 4u, hipMemcpyDeviceToHost));
+    return check_gave_up(ctx);
+}
+
 int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
 {
     PT_ENTER(ctx);
@@ -721,6 +818,7 @@ void *pt_accum_device_ptr(pt_ctx *ctx) { return ctx ? ctx->accum : nullptr; }
 int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
 {
     PT_ENTER(ctx);
+    if (ctx->window_size && device_ptr) return fail(ctx, PT_ERR_STATE, "pt_bind_accum: not available while a window is set (pt_set_window)");
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u)) return fail(ctx, PT_ERR_INVALID, "pt_bind_accum: pointer not 16-byte aligned");
     ctx->accum = device_ptr ? static_cast<float4 *>(device_ptr) : ctx->accum_owned;

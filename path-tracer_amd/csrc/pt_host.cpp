@@ -3,6 +3,7 @@
 // No GPU calls.  Built with -ffp-contract=off: Rust never fuses a*b+c, and the BVH must come
 // out identical to the reference's, node for node.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -119,6 +120,121 @@ bool parse_index(const char *&s, int count, int &out)
     else if (raw < 0) out = count + (int)raw;
     else return false;
     return out >= 0 && out < count;
+}
+
+// ---- Radiance .hdr (RGBE) decoding ------------------------------------------------------
+// The reference hands the file's bytes to image 0.24.7's HdrDecoder in strict mode and converts every
+// pixel with Rgbe8Pixel::to_hdr (src/texture.rs:179-188).  That crate is not part of the reference
+// tree; this follows its published behaviour: "#?RADIANCE" signature, header lines up to an empty
+// line, FORMAT must be 32-bit_rle_rgbe, dimensions "-Y <height> +X <width>", per-scanline choice
+// between the per-component run-length coding (first pixel 2,2,<128,*) and the old coding in which
+// a 1,1,1,n pixel repeats the previous one n times (consecutive markers multiply by 256).
+struct HdrReader {
+    const uint8_t *p;
+    size_t n, at;
+    bool byte(uint8_t &b)
+    {
+        if (at >= n) return false;
+        b = p[at++];
+        return true;
+    }
+    bool bytes(uint8_t *dst, size_t count)
+    {
+        if (n - at < count) return false;
+        std::memcpy(dst, p + at, count);
+        at += count;
+        return true;
+    }
+    // one line without its '\n'; false at the end of the data with nothing read
+    bool line(std::string &out)
+    {
+        out.clear();
+        if (at >= n) return false;
+        while (at < n && p[at] != '\n') out.push_back((char)p[at++]);
+        if (at < n) at++;
+        return true;
+    }
+};
+
+std::string trimmed(const std::string &s)
+{
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) a++;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+bool parse_u32_strict(const std::string &s, uint32_t &v)
+{
+    // what str::parse::<u32> takes: an optional '+', then digits only, no overflow
+    size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
+    if (i >= s.size()) return false;
+    uint64_t acc = 0;
+    for (; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        acc = acc * 10 + (uint64_t)(s[i] - '0');
+        if (acc > 0xFFFFFFFFull) return false;
+    }
+    v = (uint32_t)acc;
+    return true;
+}
+
+// one colour component of a run-length coded scanline: literal groups of up to 128 values, runs of up to 127
+bool hdr_component(HdrReader &r, uint8_t *rgbe, size_t width, int comp, std::string &why)
+{
+    size_t pos = 0;
+    uint8_t buf[128];
+    while (pos < width) {
+        uint8_t rl;
+        if (!r.byte(rl)) { why = "data ends inside a scanline"; return false; }
+        if (rl == 0) { why = "zero-length group in a scanline"; return false; }  // (the crate would never finish here)
+        if (rl <= 128) {
+            if (pos + rl > width) { why = "scanline longer than the image is wide"; return false; }
+            if (!r.bytes(buf, rl)) { why = "data ends inside a scanline"; return false; }
+            for (size_t k = 0; k < rl; k++) rgbe[4 * (pos + k) + comp] = buf[k];
+        } else {
+            rl = (uint8_t)(rl - 128);
+            if (pos + rl > width) { why = "scanline longer than the image is wide"; return false; }
+            uint8_t value;
+            if (!r.byte(value)) { why = "data ends inside a scanline"; return false; }
+            for (size_t k = 0; k < rl; k++) rgbe[4 * (pos + k) + comp] = value;
+        }
+        pos += rl;
+    }
+    return true;
+}
+
+bool hdr_scanline(HdrReader &r, uint8_t *rgbe, size_t width, std::string &why)
+{
+    uint8_t fb[4];
+    if (!r.bytes(fb, 4)) { why = "data ends before a scanline"; return false; }
+    if (fb[0] == 2 && fb[1] == 2 && fb[2] < 128) {
+        for (int comp = 0; comp < 4; comp++)
+            if (!hdr_component(r, rgbe, width, comp, why)) return false;
+        return true;
+    }
+    // old coding
+    if (fb[0] == 1 && fb[1] == 1 && fb[2] == 1) { why = "scanline starts with a run marker"; return false; }
+    std::memcpy(rgbe, fb, 4);
+    size_t x = 1, mult = 1;
+    uint8_t prev[4] = {fb[0], fb[1], fb[2], fb[3]};
+    while (x < width) {
+        uint8_t pix[4];
+        if (!r.bytes(pix, 4)) { why = "data ends inside a scanline"; return false; }
+        if (pix[0] == 1 && pix[1] == 1 && pix[2] == 1) {
+            const size_t rl = (size_t)pix[3] * mult;
+            mult *= 256;
+            if (x + rl > width) { why = "scanline longer than the image is wide"; return false; }
+            for (size_t k = 0; k < rl; k++) std::memcpy(rgbe + 4 * (x + k), prev, 4);
+            x += rl;
+        } else {
+            mult = 1;
+            std::memcpy(prev, pix, 4);
+            std::memcpy(rgbe + 4 * x, pix, 4);
+            x += 1;
+        }
+    }
+    return true;
 }
 
 }  // namespace
@@ -274,6 +390,61 @@ int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n
         }
         out[t].albedo[0] = out[t].albedo[1] = out[t].albedo[2] = 1.0f;  // model.rs:199-200
         out[t].material = 0;
+    }
+    return PT_OK;
+}
+
+int pt_hdr_decode(const void *data, size_t n_bytes, float *rgba_out, size_t capacity_pixels, uint32_t *width, uint32_t *height)
+{
+    if (!data || !width || !height) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: null pointer");
+    HdrReader r{static_cast<const uint8_t *>(data), n_bytes, 0};
+    static const char kSignature[] = "#?RADIANCE";
+    if (n_bytes < 10 || std::memcmp(r.p, kSignature, 10) != 0) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: Radiance HDR signature not found");
+    r.at = 10;
+    std::string line;
+    r.line(line);  // rest of the signature line
+    for (;;) {
+        if (!r.line(line)) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: data ends inside the header");
+        if (line.empty()) break;
+        if (line[0] == '#') continue;
+        const size_t eq = line.find('=');
+        if (eq != std::string::npos && line.compare(0, eq, "FORMAT") == 0 && trimmed(line.substr(eq + 1)) != "32-bit_rle_rgbe")
+            return host_fail(PT_ERR_INVALID, "pt_hdr_decode: unsupported FORMAT " + trimmed(line.substr(eq + 1)));
+        // EXPOSURE, PIXASPECT, COLORCORR and unknown keys do not change the decoded pixels
+    }
+    if (!r.line(line)) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: data ends before the dimensions line");
+    std::vector<std::string> parts;
+    for (size_t i = 0; i < line.size();) {
+        while (i < line.size() && std::isspace((unsigned char)line[i])) i++;
+        size_t j = i;
+        while (j < line.size() && !std::isspace((unsigned char)line[j])) j++;
+        if (j > i) parts.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    uint32_t w = 0, h = 0;
+    if (parts.size() != 4) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: malformed dimensions line");
+    if (parts[0] != "-Y" || parts[2] != "+X") return host_fail(PT_ERR_INVALID, "pt_hdr_decode: unsupported orientation " + parts[0] + " " + parts[2]);
+    if (!parse_u32_strict(parts[1], h) || !parse_u32_strict(parts[3], w)) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: malformed dimensions line");
+    if (w == 0 || h == 0) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: empty image");
+    if ((uint64_t)w * h * 3 > 0xFFFFFFFFull) return host_fail(PT_ERR_LIMIT, "pt_hdr_decode: image dimensions too large");
+    *width = w;
+    *height = h;
+    if (!rgba_out) return PT_OK;
+    if (capacity_pixels < (size_t)w * h) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: output buffer too small");
+    std::vector<uint8_t> row((size_t)w * 4);
+    std::string why;
+    for (uint32_t y = 0; y < h; y++) {
+        if (!hdr_scanline(r, row.data(), w, why)) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: " + why + " (row " + std::to_string(y) + ")");
+        float *dst = rgba_out + (size_t)y * w * 4;
+        for (uint32_t x = 0; x < w; x++) {
+            // Rgbe8Pixel::to_hdr: mantissa * 2^(e - 136), black when e == 0; alpha 1 (texture.rs:184-185)
+            const uint8_t *px = &row[4 * (size_t)x];
+            const float scale = px[3] ? std::ldexp(1.0f, (int)px[3] - 136) : 0.0f;
+            dst[4 * x + 0] = scale * (float)px[0];
+            dst[4 * x + 1] = scale * (float)px[1];
+            dst[4 * x + 2] = scale * (float)px[2];
+            dst[4 * x + 3] = 1.0f;
+        }
     }
     return PT_OK;
 }

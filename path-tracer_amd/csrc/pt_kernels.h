@@ -116,6 +116,11 @@ struct PtRayQuery {
 hipError_t pt_launch_ray_query(const PtRayQuery &q, uint32_t stack_depth, hipStream_t stream);
 size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth);
 
+// One finished frame into its slot of the rgba8unorm frame ring and onto the running sums; clears `frame`.
+hipError_t pt_launch_window_push(float4 *frame, float4 *accum, uint32_t *slot, uint32_t n_pixels, hipStream_t stream);
+// Mean of the newest `count` ring frames (newest at slot `newest`, older ones before it, wrapping), as copy.wgsl sums them.
+hipError_t pt_launch_window_mean(const uint32_t *ring, uint32_t n_pixels, uint32_t ring_frames, uint32_t newest, uint32_t count,
+                                 float4 *out_f, uint32_t *out_u8, hipStream_t stream);
 // mode 0: mean rgba32f -> out_f; mode 1: clamp + rgba8unorm quantise -> out_u8
 hipError_t pt_launch_resolve(const float4 *accum, uint32_t n_pixels, float4 *out_f, uint32_t *out_u8, int mode,
                              hipStream_t stream);

@@ -1766,6 +1766,59 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4 *accum, uint3
     }
 }
 
+// ---- the reference's display window: the newest n frames as rgba8unorm textures ------------------
+// compute.wgsl:124-127 stores every frame's colour into an rgba8unorm texture and copy.wgsl:27-37 shows the
+// mean of the newest n of them (renderer.rs:492-516 shifts the textures down by one before every frame).
+// Here the frames live in a ring of packed texels instead of being copied from texture to texture.
+__device__ __forceinline__ uint32_t unorm8_store(float4 c)
+{
+    auto q = [](float v) -> uint32_t {
+        v = pt_min(pt_max(v, 0.0f), 1.0f);  // NaN -> 0
+        return (uint32_t)pt_rint(v * 255.0f);
+    };
+    return q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+}
+
+// One finished frame (colour in .xyz, 1 in .w where the dispatch covered the pixel, zeros elsewhere): its texel
+// into the ring slot, its colour onto the running sums exactly as the megakernel adds it, and the frame
+// buffer back to zero for the next frame.
+__global__ __launch_bounds__(256) void window_push_kernel(float4 *frame, float4 *accum, uint32_t *slot, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 f = frame[i];
+    slot[i] = unorm8_store(f);  // an uncovered pixel keeps the texture's initial zeros
+    if (f.w != 0.0f) {
+        float4 a = accum[i];
+        a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
+        accum[i] = a;
+        frame[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// copy.wgsl:27-37: colour = sum over i < count of textures[i] (newest first), divided by count.
+__global__ __launch_bounds__(256) void window_mean_kernel(const uint32_t *ring, uint32_t n, uint32_t ring_frames, uint32_t newest,
+                                                          uint32_t count, float4 *out_f, uint32_t *out_u8)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 color = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t slot = newest;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t t = ring[(size_t)slot * n + i];
+        // unorm8 -> f32 as a texture load does it: c / 255
+        color.x += (float)(t & 255u) / 255.0f;
+        color.y += (float)((t >> 8) & 255u) / 255.0f;
+        color.z += (float)((t >> 16) & 255u) / 255.0f;
+        color.w += (float)(t >> 24) / 255.0f;
+        slot = slot ? slot - 1u : ring_frames - 1u;
+    }
+    const float c = (float)count;
+    color = make_float4(color.x / c, color.y / c, color.z / c, color.w / c);
+    if (out_f) out_f[i] = color;
+    if (out_u8) out_u8[i] = unorm8_store(color);
+}
+
 // ---- equirectangular -> cube map: shaders/equirectangular.wgsl:12-81 -----------------------
 __global__ __launch_bounds__(256) void equirect_kernel(const float4 *src, uint32_t src_w, uint32_t src_h, float4 *dst, uint32_t size)
 {
@@ -1971,6 +2024,21 @@ hipError_t pt_launch_resolve(const float4 *accum, uint32_t n_pixels, float4 *out
 {
     if (n_pixels == 0) return hipSuccess;
     hipLaunchKernelGGL(resolve_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, accum, n_pixels, out_f, out_u8, mode);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_window_push(float4 *frame, float4 *accum, uint32_t *slot, uint32_t n_pixels, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_push_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, frame, accum, slot, n_pixels);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_window_mean(const uint32_t *ring, uint32_t n_pixels, uint32_t ring_frames, uint32_t newest, uint32_t count,
+                                 float4 *out_f, uint32_t *out_u8, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_mean_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, ring, n_pixels, ring_frames, newest, count, out_f, out_u8);
     return hipGetLastError();
 }
 

@@ -152,6 +152,91 @@ def test_equirect_to_cube_matches_oracle(pt, po, scenes):
     r.close()
 
 
+def test_hdr_file_to_sky_cube_matches_oracle(pt, po, scenes):
+    """The whole of CubeTexture::from_equirectangular_hdri (src/texture.rs:172-270): .hdr bytes -> panorama -> cube."""
+    pano = scenes.sky_equirect(128, 64)[..., :3].astype(np.float64)
+    mant, expo = np.frexp(pano.max(axis=-1))                 # shared exponent of the largest channel
+    rgbe = np.zeros((64, 128, 4), np.uint8)
+    rgbe[..., :3] = np.clip(pano / np.ldexp(1.0, expo)[..., None] * 256.0, 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(pano.max(axis=-1) < 1e-32, 0, expo + 128)
+    data = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 64 +X 128\n" + rgbe.tobytes()  # 128 px rows, flat coding
+    decoded = pt.decode_hdr(data)
+    want_pano = po.hdr_decode(data)
+    _exact(decoded, want_pano, "decoded panorama")
+    assert np.abs(decoded[..., :3] - pano).max() <= pano.max() / 128.0
+    r = pt.Renderer(scenes.three_balls(), 32, 20, settings=pt.Settings(1, 4, 1e-4, 1000.0))
+    r.set_sky_equirect(decoded, 32)
+    _exact(r.read_sky_cube(32), po.equirect_to_cube(want_pano, 32), "cube texels from the .hdr")
+    r.close()
+
+
+def test_display_window_matches_oracle(pt, po, scenes):
+    """ProgressiveRendering + copy.wgsl (renderer.rs:492-516, 613-646): the newest frames as 8-bit textures and
+    their mean, through single frames, a fused call, a reset and more frames than the window holds."""
+    scene = scenes.cornell()
+    sky = scenes.sky_cube_direct(8)
+    st = pt.Settings(2, 4, 1e-4, 1000.0)
+    w, h = 72, 40  # reference dispatch covers 64 x 32 of it
+    flags = pt.PT_FLAG_REFERENCE_DISPATCH
+    r = pt.Renderer(scene, w, h, settings=st, flags=flags)
+    r.set_sky_cube(sky)
+    r.set_window(3)
+    osc = po.from_scene(scene, w, h, st, sky, flags)
+    win = po.ProgressiveWindow(3)
+    acc = np.zeros((h, w, 4), np.float32)
+
+    def oracle_frames(times):
+        for t in times:
+            frame, *_ = osc.render(t)
+            win.frame(frame)
+            acc[...] = acc + frame
+
+    def check(what):
+        mean, q, n = r.read_window()
+        want = win.displayed()
+        assert n == win.shown, what
+        _exact(mean, want, what + ": displayed mean")
+        assert np.array_equal(q, np.rint(np.clip(want, 0, 1) * np.float32(255.0)).astype(np.uint8)), what
+        _exact(r.read_sum(), acc, what + ": running sums")
+
+    r.render(5)
+    oracle_frames([5])
+    assert r.window_frames_shown() == 0
+    with pytest.raises(pt.PtError):  # the reference's first frame averages zero textures
+        r.read_window()
+    r.render(6)
+    oracle_frames([6])
+    check("second frame")
+    assert r.window_frames_shown() == 1
+    r.render_frames(10, 3, 4)  # fused call: times 10, 13, 16, 19; the window is full afterwards
+    oracle_frames([10, 13, 16, 19])
+    check("after a fused call")
+    assert r.window_frames_shown() == 3 and (r.read_window()[0][32:] == 0).all()
+    r.reset_ready_samples()
+    win.reset_ready_samples()
+    acc[...] = 0
+    r.render(30)
+    oracle_frames([30])
+    check("first frame after a reset")
+    assert r.window_frames_shown() == 1
+    r.render_frames(31, 1, 2)
+    oracle_frames([31, 32])
+    check("window refilling")
+    # without the window the sums are the same bits
+    r2 = pt.Renderer(scene, w, h, settings=st, flags=flags)
+    r2.set_sky_cube(sky)
+    r2.render(30)
+    r2.render_frames(31, 1, 2)
+    _exact(r.read_sum(), r2.read_sum(), "sums with and without a window")
+    r2.close()
+    r.set_window(0)
+    with pytest.raises(pt.PtError):
+        r.read_window()
+    with pytest.raises(pt.PtError):
+        r.set_window(257)
+    r.close()
+
+
 def test_readouts(pt, scenes):
     scene = scenes.three_balls()
     r = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0))

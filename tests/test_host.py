@@ -117,3 +117,116 @@ def test_default_camera_basis(pt, scenes):
     assert abs(cam.forward[2] + 1) < 1e-6 and abs(cam.forward[0]) < 1e-6 and cam.forward[0] != 0
     assert np.allclose(cam.right, [1, 0, 0], atol=1e-6) and np.allclose(cam.up, [0, 1, 0], atol=1e-6)
     assert cam.buffer().tobytes()[12:16] == np.float32(1.0).tobytes()      # focal length at offset 12
+
+
+# ---- Radiance .hdr decoding (src/texture.rs:179-188) -------------------------------------------------
+def _rgbe_pixels(rng, h, w):
+    px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    px[..., 3] = rng.integers(100, 150, (h, w))       # exponents around 1.0
+    px[rng.random((h, w)) < 0.1, 3] = 0                 # e == 0: black whatever the mantissas say
+    px[0, 0] = (200, 100, 50, 1)                        # 2^-135: a denormal scale
+    px[0, 1] = (255, 255, 255, 255)
+    for y in range(h):                                  # horizontal runs, so the run-length coders have work
+        x0 = int(rng.integers(0, max(1, w - 4)))
+        px[y, x0:x0 + int(rng.integers(2, 200))] = px[y, x0]
+    if w > 650:
+        px[1, 10:611] = px[1, 10]                      # a 600-pixel run: two consecutive markers in the old coding
+    # keep pixel values that the old coding reads as markers (1,1,1,*) or a new-style row start (2,2,<128) out
+    px[(px[..., 0] == 1) & (px[..., 1] == 1) & (px[..., 2] == 1), 0] = 3
+    px[(px[..., 0] == 2) & (px[..., 1] == 2), 1] = 7
+    return px
+
+
+def _hdr_header(h, w, extra=b""):
+    return b"#?RADIANCE\n# made by a test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=2.5\n" + extra + b"\n" + f"-Y {h} +X {w}\n".encode()
+
+
+def _encode_new_rle(px):
+    out = bytearray()
+    h, w, _ = px.shape
+    for y in range(h):
+        out += bytes([2, 2, (w >> 8) & 0x7F, w & 0xFF])
+        for comp in range(4):
+            row = px[y, :, comp]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, int(row[x])])
+                    x += run
+                else:
+                    lit = x
+                    while lit < w and lit - x < 128 and not (lit + 2 < w and row[lit] == row[lit + 1] == row[lit + 2]):
+                        lit += 1
+                    lit = max(lit, x + 1)
+                    out += bytes([lit - x]) + row[x:lit].tobytes()
+                    x = lit
+    return bytes(out)
+
+
+def _encode_old_rle(px):
+    out = bytearray()
+    h, w, _ = px.shape
+    for y in range(h):
+        x = 0
+        while x < w:
+            out += px[y, x].tobytes()
+            run = 0
+            while x + 1 + run < w and (px[y, x + 1 + run] == px[y, x]).all():
+                run += 1
+            x += 1
+            if run >= 2:
+                lo, hi = run & 0xFF, run >> 8       # consecutive markers: n, then n * 256
+                if lo:
+                    out += bytes([1, 1, 1, lo])
+                    if hi:
+                        out += bytes([1, 1, 1, hi])
+                    x += run
+                elif hi:
+                    out += px[y, x].tobytes()       # break the chain so the next marker counts singly
+                    out += bytes([1, 1, 1, 255])
+                    x += 1 + 255
+    return bytes(out)
+
+
+@pytest.mark.parametrize("coder", ["new", "old", "flat"])
+def test_hdr_decode_matches_oracle(pt, po, coder):
+    rng = np.random.default_rng(5)
+    h, w = 9, 700
+    px = _rgbe_pixels(rng, h, w)
+    body = {"new": _encode_new_rle, "old": _encode_old_rle, "flat": lambda a: a.tobytes()}[coder](px)
+    data = _hdr_header(h, w) + body
+    got = pt.decode_hdr(data)
+    want = po.hdr_decode(data)
+    assert got.shape == (h, w, 4) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and both agree with the formula applied to the pixels that went in
+    e = px[..., 3].astype(np.int32)
+    ref = px[..., :3].astype(np.float64) * np.where(e == 0, 0.0, np.ldexp(1.0, e - 136))[..., None]
+    assert np.array_equal(got[..., :3].astype(np.float64), ref.astype(np.float32).astype(np.float64)) and (got[..., 3] == 1.0).all()
+    assert got[0, 0, 0] == np.float32(200.0 * 2.0 ** -135) and got[0, 0, 0] > 0.0
+
+
+def test_hdr_decode_rejects_bad_files(pt, po):
+    px = _rgbe_pixels(np.random.default_rng(6), 4, 64)
+    good = _hdr_header(4, 64) + _encode_new_rle(px)
+    pt.decode_hdr(good)
+    bad = {
+        "signature": b"#?RGBE\n" + good[11:],
+        "format": _hdr_header(4, 64, b"FORMAT=32-bit_rle_xyze\n").replace(b"FORMAT=32-bit_rle_rgbe\n", b"", 1) + _encode_new_rle(px),
+        "orientation": good.replace(b"-Y 4 +X 64", b"+Y 4 +X 64"),
+        "dimensions": good.replace(b"-Y 4 +X 64", b"-Y 4 +X 64 7"),
+        "number": good.replace(b"-Y 4 +X 64", b"-Y 4 +X 6x"),
+        "empty": good.replace(b"-Y 4 +X 64", b"-Y 0 +X 64"),
+        "truncated": good[:-5],
+        "no header end": b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n",
+        "too long": _hdr_header(4, 64) + bytes([2, 2, 0, 64, 128 + 65, 9]),
+        "zero group": _hdr_header(4, 64) + bytes([2, 2, 0, 64, 0, 0, 0, 0]),
+        "marker first": _hdr_header(4, 64) + bytes([1, 1, 1, 5]) + bytes(64 * 16),
+    }
+    for name, data in bad.items():
+        with pytest.raises(pt.PtError):
+            pt.decode_hdr(data)
+        with pytest.raises(ValueError):
+            po.hdr_decode(data)

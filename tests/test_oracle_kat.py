@@ -227,3 +227,24 @@ def test_depth_exhaustion_returns_throughput_and_absorption_sees_sky(pt, po):
     assert set(vals.tolist()) <= {0.125, 3.5, 1.75, 0.875}
     assert 0.125 in vals.tolist()
     assert (acc[..., 3] == 1).all()
+
+
+def test_progressive_window_bookkeeping(po):
+    """renderer.rs:539-541, 560, 623-645 by hand: ready_samples starts at 0, the copy pass uses the count from
+    before the increment, reset_ready_samples sets 1; texels are round(clamp(c) * 255) and the mean is over 8-bit values."""
+    win = po.ProgressiveWindow(3)
+    shown = []
+    for k in range(5):
+        win.frame(np.full((1, 2, 4), 0.1 * (k + 1), np.float32))
+        shown.append(win.shown)
+    assert shown == [0, 1, 2, 3, 3]
+    # newest three frames hold 0.5, 0.4, 0.3 -> texels 128 (127.5 rounds to even), 102, 76 (76.5 -> 76)
+    want = (np.float32(128) / np.float32(255) + np.float32(102) / np.float32(255) + np.float32(76) / np.float32(255)) / np.float32(3)
+    assert (win.displayed() == want).all()
+    win.reset_ready_samples()
+    win.frame(np.array([[[2.0, -1.0, np.nan, 1.0]]], np.float32))
+    assert win.shown == 1 and (win.displayed() == np.array([1.0, 0.0, 0.0, 1.0], np.float32)).all()
+    fresh = po.ProgressiveWindow(4)
+    fresh.frame(np.zeros((1, 1, 4), np.float32))
+    with pytest.raises(ValueError):
+        fresh.displayed()
