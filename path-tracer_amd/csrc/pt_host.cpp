@@ -3,12 +3,15 @@
 // No GPU calls.  Built with -ffp-contract=off: Rust never fuses a*b+c, and the BVH must come
 // out identical to the reference's, node for node.
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/ptrt.h"
@@ -27,33 +30,73 @@ int host_fail(int code, const std::string &msg)
 // Triangle::centroid, src/model.rs:42-48
 inline float centroid_axis(const PtTriangle &t, int axis) { return (t.a[axis] + t.b[axis] + t.c[axis]) / 3.0f; }
 
+inline PtNode empty_node()
+{
+    PtNode n;  // Node::default, bvh.rs:16-25
+    for (int ax = 0; ax < 3; ax++) {
+        n.min_corner[ax] = 3.40282347e+38f;
+        n.max_corner[ax] = -3.40282347e+38f;
+    }
+    n.left_child_index = 0;
+    n.triangle_count = 0;
+    return n;
+}
+
+// Builds the tree of Bvh::from_triangles (src/scene/bvh.rs:34-162).  The node numbering is that of the
+// reference's recursion: a split takes the next two free slots for its children, then the whole left
+// subtree is built before the right one.  Big inputs are built by several threads with the same result:
+// the top of the tree is split one node at a time (largest first; bounds of big nodes reduced in
+// parallel), every remaining subtree is built independently with numbers relative to its root, and a last
+// pass over the top of the tree hands out the global numbers in recursion order and relocates the
+// subtrees.
 struct BvhBuilder {
-    PtNode *nodes;
     uint32_t *idx;
     const PtTriangle *tris;
-    uint32_t used;
+    unsigned n_threads = 1;
 
-    // Bvh::update_bounds, src/scene/bvh.rs:68-89.  f32::min/max ignore a NaN operand; which of +0/-0
-    // they return on a tie is not specified, here the earlier value stays.
-    void update_bounds(uint32_t ni)
+    // Bvh::update_bounds, src/scene/bvh.rs:68-89, over idx[first .. first+count).  f32::min/max ignore a NaN
+    // operand; which of +0/-0 they return on a tie is not specified, here the earlier value stays.
+    void bounds_of(uint32_t first, uint32_t count, float mn[3], float mx[3]) const
     {
-        PtNode &n = nodes[ni];
-        for (uint32_t i = 0; i < n.triangle_count; i++) {
-            const PtTriangle &t = tris[idx[n.left_child_index + i]];
+        for (uint32_t i = 0; i < count; i++) {
+            const PtTriangle &t = tris[idx[first + i]];
             const float *verts[3] = {t.a, t.b, t.c};
             for (const float *v : verts)
                 for (int ax = 0; ax < 3; ax++) {
-                    if (v[ax] < n.min_corner[ax]) n.min_corner[ax] = v[ax];
-                    if (v[ax] > n.max_corner[ax]) n.max_corner[ax] = v[ax];
+                    if (v[ax] < mn[ax]) mn[ax] = v[ax];
+                    if (v[ax] > mx[ax]) mx[ax] = v[ax];
                 }
         }
     }
 
-    // Bvh::subdivide, src/scene/bvh.rs:91-162.  Returns false when the node stays a leaf,
-    // otherwise the two children (left, left+1) are allocated and bounded.
-    bool split(uint32_t ni)
+    void update_bounds(PtNode &n) const
     {
-        const PtNode node = nodes[ni];
+        const uint32_t first = n.left_child_index, count = n.triangle_count;
+        const unsigned parts = (n_threads > 1 && count >= (1u << 16)) ? n_threads : 1;
+        if (parts == 1) {
+            bounds_of(first, count, n.min_corner, n.max_corner);
+            return;
+        }
+        // chunks in index order, merged in that order with the same strict comparisons: on a tie the value
+        // of the earliest triangle stays, as in the single loop
+        std::vector<PtNode> part(parts, empty_node());
+        std::vector<std::thread> pool;
+        for (unsigned k = 0; k < parts; k++) {
+            const uint32_t lo = (uint32_t)((uint64_t)count * k / parts), hi = (uint32_t)((uint64_t)count * (k + 1) / parts);
+            pool.emplace_back([this, &part, k, first, lo, hi] { bounds_of(first + lo, hi - lo, part[k].min_corner, part[k].max_corner); });
+        }
+        for (std::thread &t : pool) t.join();
+        for (unsigned k = 0; k < parts; k++)
+            for (int ax = 0; ax < 3; ax++) {
+                if (part[k].min_corner[ax] < n.min_corner[ax]) n.min_corner[ax] = part[k].min_corner[ax];
+                if (part[k].max_corner[ax] > n.max_corner[ax]) n.max_corner[ax] = part[k].max_corner[ax];
+            }
+    }
+
+    // Bvh::subdivide, src/scene/bvh.rs:91-162, for one node: false when it stays a leaf, otherwise its
+    // triangle range is partitioned and the two children come back with ranges and bounds.
+    bool split(const PtNode &node, PtNode &left, PtNode &right) const
+    {
         if (node.triangle_count <= 2) return false;
         const float extent[3] = {node.max_corner[0] - node.min_corner[0], node.max_corner[1] - node.min_corner[1],
                                  node.max_corner[2] - node.min_corner[2]};
@@ -71,38 +114,155 @@ struct BvhBuilder {
         }
         const uint32_t left_count = i - node.left_child_index;
         if (left_count == 0 || left_count == node.triangle_count) return false;
-
-        const uint32_t li = used++, ri = used++;
-        nodes[li].left_child_index = node.left_child_index;
-        nodes[li].triangle_count = left_count;
-        nodes[ri].left_child_index = i;
-        nodes[ri].triangle_count = node.triangle_count - left_count;
-        nodes[ni].left_child_index = li;
-        nodes[ni].triangle_count = 0;
-        update_bounds(li);
-        update_bounds(ri);
+        left = right = empty_node();
+        left.left_child_index = node.left_child_index;
+        left.triangle_count = left_count;
+        right.left_child_index = i;
+        right.triangle_count = node.triangle_count - left_count;
+        update_bounds(left);
+        update_bounds(right);
         return true;
     }
 
-    // Same visiting order as the reference's recursion (whole left subtree before the right
-    // one, which fixes the node numbering) with an explicit stack, so clustered input cannot
-    // overflow the call stack.
-    void build(uint32_t n_tris)
+    // The subtree below nodes[root], numbered from `used` on.  Same visiting order as the reference's
+    // recursion with an explicit stack, so clustered input cannot overflow the call stack.
+    template <typename Nodes>
+    void build_subtree(Nodes &nodes, uint32_t root, uint32_t &used) const
     {
-        nodes[0].left_child_index = 0;
-        nodes[0].triangle_count = n_tris;
-        used = 1;
-        update_bounds(0);
-        std::vector<uint32_t> todo{0};
+        std::vector<uint32_t> todo{root};
+        PtNode l, r;
         while (!todo.empty()) {
             const uint32_t ni = todo.back();
             todo.pop_back();
-            if (split(ni)) {
-                const uint32_t li = nodes[ni].left_child_index;
-                todo.push_back(li + 1);
-                todo.push_back(li);
+            if (!split(nodes[ni], l, r)) continue;
+            const uint32_t li = used;
+            used += 2;
+            store(nodes, li, l, r);
+            nodes[ni].left_child_index = li;
+            nodes[ni].triangle_count = 0;
+            todo.push_back(li + 1);
+            todo.push_back(li);
+        }
+    }
+    static void store(PtNode *nodes, uint32_t li, const PtNode &l, const PtNode &r) { nodes[li] = l; nodes[li + 1] = r; }
+    static void store(std::vector<PtNode> &nodes, uint32_t li, const PtNode &l, const PtNode &r)
+    {
+        if (nodes.size() < (size_t)li + 2) nodes.resize((size_t)li + 2);
+        nodes[li] = l;
+        nodes[li + 1] = r;
+    }
+
+    // returns the number of nodes used
+    uint32_t build(PtNode *nodes, uint32_t n_tris)
+    {
+        PtNode root = empty_node();
+        root.triangle_count = n_tris;
+        update_bounds(root);
+        if (n_threads <= 1 || n_tris < (1u << 16)) {
+            nodes[0] = root;
+            uint32_t used = 1;
+            build_subtree(nodes, 0, used);
+            return used;
+        }
+
+        // the top of the tree, split largest node first until there is enough independent work
+        struct Top {
+            PtNode rec;
+            int left = -1, right = -1;  // children in `top`, or -1: a subtree for the threads (or a leaf)
+        };
+        std::vector<Top> top;
+        top.push_back({root});
+        auto smaller = [&top](int a, int b) { return top[a].rec.triangle_count < top[b].rec.triangle_count; };
+        std::vector<int> open{0};  // heap of unsplit top nodes, largest on top
+        const size_t wanted = (size_t)n_threads * 16;
+        while (!open.empty() && open.size() < wanted) {
+            std::pop_heap(open.begin(), open.end(), smaller);
+            const int t = open.back();
+            if (top[t].rec.triangle_count < 4096u) break;  // (the largest is small: nothing left worth splitting here)
+            open.pop_back();
+            PtNode l, r;
+            if (!split(top[t].rec, l, r)) continue;  // stays a leaf; no longer open
+            top[t].left = (int)top.size();
+            top.push_back({l});
+            top[t].right = (int)top.size();
+            top.push_back({r});
+            for (int c : {top[t].left, top[t].right}) {
+                open.push_back(c);
+                std::push_heap(open.begin(), open.end(), smaller);
             }
         }
+
+        // every top node without children: its subtree, numbered from 1 relative to its root at 0
+        std::vector<int> jobs;
+        for (size_t t = 0; t < top.size(); t++)
+            if (top[t].left < 0) jobs.push_back((int)t);
+        std::sort(jobs.begin(), jobs.end(), [&top](int a, int b) { return top[a].rec.triangle_count > top[b].rec.triangle_count; });
+        std::vector<std::vector<PtNode>> sub(top.size());
+        std::atomic<size_t> next{0};
+        const unsigned serial_threads = n_threads;
+        n_threads = 1;  // inside the jobs bounds are computed by the job's own thread
+        {
+            std::vector<std::thread> pool;
+            for (unsigned k = 0; k < serial_threads; k++)
+                pool.emplace_back([&] {
+                    for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                        std::vector<PtNode> &mine = sub[jobs[j]];
+                        mine.assign(1, top[jobs[j]].rec);
+                        uint32_t used = 1;
+                        build_subtree(mine, 0, used);
+                        mine.resize(used);
+                    }
+                });
+            for (std::thread &t : pool) t.join();
+        }
+        n_threads = serial_threads;
+
+        // global numbers in recursion order: a split node's children take the next two slots, then come all
+        // nodes below the left child, then all below the right one
+        struct Move {
+            int job;
+            uint32_t base;  // global number of the subtree's local node 1
+        };
+        std::vector<Move> moves;
+        uint32_t used = 1;
+        nodes[0] = top[0].rec;
+        std::vector<std::pair<int, uint32_t>> todo{{0, 0u}};  // (top node, its global number)
+        while (!todo.empty()) {
+            const auto [t, ni] = todo.back();
+            todo.pop_back();
+            if (top[t].left >= 0) {
+                const uint32_t li = used;
+                used += 2;
+                nodes[ni] = top[t].rec;
+                nodes[ni].left_child_index = li;
+                nodes[ni].triangle_count = 0;
+                todo.push_back({top[t].right, li + 1});
+                todo.push_back({top[t].left, li});
+            } else {
+                moves.push_back({t, used});
+                nodes[ni] = sub[t][0];
+                if (sub[t].size() > 1) nodes[ni].left_child_index += used - 1u;  // an interior root: its children's number
+                used += (uint32_t)sub[t].size() - 1u;
+            }
+        }
+        next = 0;
+        {
+            std::vector<std::thread> pool;
+            for (unsigned k = 0; k < n_threads; k++)
+                pool.emplace_back([&] {
+                    for (size_t m; (m = next.fetch_add(1)) < moves.size();) {
+                        const std::vector<PtNode> &from = sub[moves[m].job];
+                        const uint32_t shift = moves[m].base - 1u;
+                        for (size_t k2 = 1; k2 < from.size(); k2++) {
+                            PtNode n = from[k2];
+                            if (n.triangle_count == 0) n.left_child_index += shift;  // interior: children's number; leaves keep their triangle range
+                            nodes[moves[m].base + (k2 - 1)] = n;
+                        }
+                    }
+                });
+            for (std::thread &t : pool) t.join();
+        }
+        return used;
     }
 };
 
@@ -248,19 +408,19 @@ int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_
     if (n_tris == 0) return 0;  // Bvh::from_triangles returns empty vectors, bvh.rs:35-41
     if (!tris || !nodes_out || !idx_out) return host_fail(PT_ERR_INVALID, "pt_bvh_build: null pointer");
     PtNode *nodes = static_cast<PtNode *>(nodes_out);
-    const size_t cap = (size_t)n_tris * 2u - 1u;
-    for (size_t k = 0; k < cap; k++) {  // Node::default, bvh.rs:16-25
-        for (int ax = 0; ax < 3; ax++) {
-            nodes[k].min_corner[ax] = 3.40282347e+38f;
-            nodes[k].max_corner[ax] = -3.40282347e+38f;
-        }
-        nodes[k].left_child_index = 0;
-        nodes[k].triangle_count = 0;
-    }
     for (uint32_t k = 0; k < n_tris; k++) idx_out[k] = k;
-    BvhBuilder b{nodes, idx_out, static_cast<const PtTriangle *>(tris), 0};
-    b.build(n_tris);
-    return (int64_t)b.used;
+    BvhBuilder b{idx_out, static_cast<const PtTriangle *>(tris)};
+    b.n_threads = std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+    if (const char *env = std::getenv("PTRT_BUILD_THREADS")) b.n_threads = (unsigned)std::max(1, std::atoi(env));
+    uint32_t used = 0;
+    try {
+        used = b.build(nodes, n_tris);
+    } catch (const std::exception &e) {
+        return host_fail(PT_ERR_NOMEM, std::string("pt_bvh_build: ") + e.what());
+    }
+    const size_t cap = (size_t)n_tris * 2u - 1u;
+    for (size_t k = used; k < cap; k++) nodes[k] = empty_node();  // Node::default; the reference truncates them away, bvh.rs:44, 64
+    return (int64_t)used;
 }
 
 int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3], uint32_t material,

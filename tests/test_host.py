@@ -61,6 +61,20 @@ def test_bvh_builder_matches_oracle(pt, po, scenes, maker):
     assert nodes.tobytes() == onodes.tobytes()
 
 
+def test_bvh_builder_threads_give_the_same_tree(pt, po, scenes, monkeypatch):
+    """Meshes of 65 536 triangles and more are built by several threads: same nodes, same index permutation as
+    one thread and as the oracle's recursion, including duplicated geometry (ties everywhere) and a signed zero."""
+    one = scenes.blob_mesh(60)
+    tris = np.concatenate([one, one, scenes.blob_mesh(40, center=(3.0, 0.5, -1.0))])
+    tris["a"][7, 0] = -0.0
+    assert len(tris) >= 65536
+    want_nodes, want_idx = po.bvh_build(tris)
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("PTRT_BUILD_THREADS", threads)
+        nodes, idx = pt.bvh_build(tris)
+        assert nodes.tobytes() == want_nodes.tobytes() and np.array_equal(idx, want_idx), threads
+
+
 def test_bvh_empty_and_bad_arguments(pt):
     nodes, idx = pt.bvh_build(np.zeros(0, pt.TRIANGLE_DTYPE))
     assert len(nodes) == 0 and len(idx) == 0
