@@ -61,6 +61,7 @@
 
 #define PTO_STACK_CAP 256
 #define PTO_FLAG_REFERENCE_DISPATCH 1u
+#define PTO_FLAG_TRIANGLE_MATERIALS 2u   /* extension: triangles use their own albedo/material (model.rs:66-67) */
 
 typedef struct { float x, y, z; } v3;
 
@@ -261,7 +262,8 @@ static hit_t hit_triangle(ctx_t *cx, ray_t ray, const pto_triangle *tr, uint32_t
     const v3 hv = cross3(ray.d, e2);
     const float a = dot3(e1, hv);
     hit_t h; memset(&h, 0, sizeof h);
-    h.att = V(1.0f, 1.0f, 1.0f); h.material = 0.0f; h.prim = index;
+    h.att = V(1.0f, 1.0f, 1.0f); h.material = 0.0f; h.prim = index;   /* compute.wgsl:359-367: the record's own fields are ignored */
+    if (cx->sc->flags & PTO_FLAG_TRIANGLE_MATERIALS) { h.att = ld3(tr->albedo); h.material = (float)tr->material; }
     if (a > -0.00001f && a < 0.00001f) return h;
     const float f = 1.0f / a;
     const v3 s = vsub(ray.o, A);

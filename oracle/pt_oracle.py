@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
 FLAG_REFERENCE_DISPATCH = 1
+FLAG_TRIANGLE_MATERIALS = 2
 
 TRIANGLE_DTYPE = np.dtype(
     [("a", "<f4", 3), ("_p0", "<f4"), ("b", "<f4", 3), ("_p1", "<f4"), ("c", "<f4", 3), ("_p2", "<f4"),

@@ -43,7 +43,7 @@ struct pt_ctx {
 
     float4 *spheres = nullptr;
     uint32_t n_spheres = 0;
-    bool has_gizmo = false;
+    bool has_gizmo = false, mesh_has_gizmo = false;
     uint64_t paths = 0;  // rayColor calls since the last reset (every pixel runs every sample)
 
     float4 *nodes_alloc = nullptr;
@@ -148,6 +148,7 @@ void free_mesh(pt_ctx *ctx)
     dev_free(ctx->tri_nrm);
     ctx->n_nodes = 0;
     ctx->n_tri_slots = 0;
+    ctx->mesh_has_gizmo = false;
     ctx->root_token = 0;
     ctx->bvh_depth = 0;
 }
@@ -166,6 +167,7 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.tri_nrm = ctx->tri_nrm;
     sc.sky = ctx->sky;
     sc.sky_size = ctx->sky_size;
+    sc.tri_materials = (ctx->flags & PT_FLAG_TRIANGLE_MATERIALS) ? 1u : 0u;
     sc.t_min = ctx->settings.t_min;
     sc.t_max = ctx->settings.t_max;
     return sc;
@@ -290,7 +292,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
 int pt_set_flags(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
@@ -356,16 +358,19 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
         rec[3] = make_float4(u2f(token_of(n.left_child_index)), u2f(token_of(n.left_child_index + 1)), 0.0f, 0.0f);
     }
     // one float4 of padding: the step-wise walk reads four float4 from a triangle's address
+    bool mesh_gizmo = false;
     std::vector<float4> h_pos(3 * (size_t)n_idx + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);
     for (uint32_t k = 0; k < n_idx; k++) {
         const PtTriangle &t = tris[tri_idx[k]];
         // edges as the shader computes them (compute.wgsl:353-354)
         h_pos[3 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(tri_idx[k]));
-        h_pos[3 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], 0.0f);
+        h_pos[3 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], (float)t.material);
         h_pos[3 * (size_t)k + 2] = make_float4(t.c[0] - t.a[0], t.c[1] - t.a[1], t.c[2] - t.a[2], 0.0f);
-        h_nrm[3 * (size_t)k] = make_float4(t.na[0], t.na[1], t.na[2], 0.0f);
-        h_nrm[3 * (size_t)k + 1] = make_float4(t.nb[0], t.nb[1], t.nb[2], 0.0f);
-        h_nrm[3 * (size_t)k + 2] = make_float4(t.nc[0], t.nc[1], t.nc[2], 0.0f);
+        // albedo and material ride in the spare components; read only with PT_FLAG_TRIANGLE_MATERIALS
+        h_nrm[3 * (size_t)k] = make_float4(t.na[0], t.na[1], t.na[2], t.albedo[0]);
+        h_nrm[3 * (size_t)k + 1] = make_float4(t.nb[0], t.nb[1], t.nb[2], t.albedo[1]);
+        h_nrm[3 * (size_t)k + 2] = make_float4(t.nc[0], t.nc[1], t.nc[2], t.albedo[2]);
+        mesh_gizmo |= (t.material == 3u);
     }
 
     free_mesh(ctx);
@@ -381,6 +386,7 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
     PT_HIP(ctx, hipMemcpy(ctx->tri_nrm, h_nrm.data(), h_nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
     ctx->n_nodes = n_nodes;
     ctx->n_tri_slots = n_idx;
+    ctx->mesh_has_gizmo = mesh_gizmo;
     ctx->root_token = token_of(0);
     if (nodes[0].triangle_count == 0)
         for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
@@ -505,7 +511,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.spp = ctx->settings.samples_per_pixel;
     p.depth = ctx->settings.depth;
     p.inv_spp = 1.0f / (float)ctx->settings.samples_per_pixel;
-    p.has_gizmo = ctx->has_gizmo;
+    p.has_gizmo = ctx->has_gizmo || ((ctx->flags & PT_FLAG_TRIANGLE_MATERIALS) && ctx->mesh_has_gizmo);
     p.stride = stride;
     p.accum = ctx->accum;
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;

@@ -34,6 +34,7 @@ struct PtDeviceScene {
     // sky cube: 6 faces of sky_size^2 RGBA32F
     const float4 *sky;
     uint32_t sky_size;
+    uint32_t tri_materials;  // 1: triangles shade with their records' albedo and material (opt-in extension)
     float t_min, t_max;
 };
 

@@ -385,6 +385,10 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
         on = normalize3(n);
         h.att = V3(1.0f, 1.0f, 1.0f);  // triangle albedo/material are ignored: compute.wgsl:359-367
         h.material = 0.0f;
+        if (sc.tri_materials) {  // opt-in: the record's own albedo and material (model.rs:66-67)
+            h.att = V3(tn[0].w, tn[1].w, tn[2].w);
+            h.material = sc.tri_pos[3 * (size_t)c.index + 1].w;
+        }
         h.prim = __float_as_uint(sc.tri_pos[3 * (size_t)c.index].w);
     } else {
         const float4 s0 = sc.spheres[3 * c.index], s1 = sc.spheres[3 * c.index + 1];

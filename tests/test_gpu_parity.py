@@ -26,7 +26,8 @@ def _both(pt, po, scene, w, h, settings, sky, times, flags=0):
     r = pt.Renderer(scene, w, h, settings=settings, flags=pt.PT_FLAG_AOV | flags)
     if sky is not None:
         r.set_sky_cube(sky)
-    osc = po.from_scene(scene, w, h, settings, sky, flags=flags & 1)
+    oflags = (flags & pt.PT_FLAG_REFERENCE_DISPATCH) | (po.FLAG_TRIANGLE_MATERIALS if flags & pt.PT_FLAG_TRIANGLE_MATERIALS else 0)
+    osc = po.from_scene(scene, w, h, settings, sky, flags=oflags)
     acc = np.zeros((h, w, 4), np.float32)
     rays = 0
     for t in times:
@@ -114,4 +115,36 @@ def test_reference_dispatch_leaves_bottom_rows(pt, po, scenes):
     got = r.read_sum()
     assert np.array_equal(got.view(np.uint32), acc.view(np.uint32))
     assert not got[32:, :, :].any() and not got[:, 96:, :].any() and got[:32, :96, 3].all()
+    r.close()
+
+
+def test_triangle_materials_extension(pt, po, scenes):
+    """Opt-in: triangles shade with their own albedo and material (model.rs:66-67) instead of the shader's
+    white Lambertian (compute.wgsl:359-367).  Coloured, mirror, glass and gizmo walls; off by default."""
+    M = pt.Material
+    planes = [
+        pt.Plane((0, 0, -1), (2, 0, 0), (0, 0, 2), (0.7, 0.7, 0.7), M.Diffuse),
+        pt.Plane((0, 2, -1), (2, 0, 0), (0, 0, 2), (0.9, 0.9, 0.9), M.Diffuse),
+        pt.Plane((0, 0, -1), (2, 0, 0), (0, 2, 0), (0.9, 0.8, 0.7), M.Metal),
+        pt.Plane((0, 0, -1), (0, 0, 2), (0, 2, 0), (0.8, 0.1, 0.1), M.Diffuse),
+        pt.Plane((2, 0, -1), (0, 0, 2), (0, 2, 0), (0.1, 0.8, 0.1), M.Diffuse),
+        pt.Plane((0.5, 0.3, 0.2), (0.8, 0, 0), (0, 0.8, 0), (1.0, 1.0, 1.0), M.Dielectric),
+        pt.Plane((0.2, 1.2, 0.0), (0.5, 0, 0), (0, 0.5, 0), (0.2, 0.3, 0.9), M.Gizmo),
+    ]
+    tris = np.concatenate([p.triangles() for p in planes])
+    scene = pt.Scene(scenes.cornell().spheres, tris, scenes.default_camera())
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(3, 6, 1e-4, 1000.0)
+    r, acc, prim, tt, rays = _both(pt, po, scene, 120, 70, st, sky, [1, 2], flags=pt.PT_FLAG_TRIANGLE_MATERIALS)
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim)
+    _assert_parity(gt, tt, "primary hit t")
+    _assert_parity(r.read_sum(), acc, "radiance with triangle materials")
+    assert r.stats()["rays"] == rays
+    with_materials = r.read_sum().copy()
+    r.close()
+    # default: the same records render as white Lambertian walls, as in the shader
+    r, acc, prim, tt, rays = _both(pt, po, scene, 120, 70, st, sky, [1, 2])
+    _assert_parity(r.read_sum(), acc, "radiance, materials ignored")
+    assert r.stats()["rays"] == rays and not np.array_equal(r.read_sum(), with_materials)
     r.close()
