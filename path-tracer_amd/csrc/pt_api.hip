@@ -184,6 +184,14 @@ int ensure_gstack(pt_ctx *ctx, size_t bytes)
     return PT_OK;
 }
 
+// Tuning aid: an environment override of a launch heuristic, read at every launch (tools/sweep_*.sh);
+// unset in normal use.
+inline uint32_t env_u32(const char *name, uint32_t fallback)
+{
+    const char *e = getenv(name);
+    return e ? (uint32_t)strtoul(e, nullptr, 10) : fallback;
+}
+
 inline float u2f(uint32_t u)
 {
     float f;
@@ -545,8 +553,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     // per-tile kernel: lanes that must wait for shading before the wave runs a shading pass; long walks
     // (big meshes) favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s)
-    p.refill_lanes = use_pool ? 64 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48);
-    if (const char *env = getenv("PTRT_REFILL_LANES")) p.refill_lanes = (uint32_t)atoi(env);  // tuning aid
+    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 64 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48));
 
     PtSchedule sch{};
     sch.cost = ctx->tile_cost;
@@ -554,15 +561,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.tile_items = ctx->tile_items;
     sch.cost_valid = &ctx->cost_valid;
     // pooled kernel: a pixel's frames run one after the other, so costly tiles need short items
-    uint32_t per_slot = use_pool ? 44 : 2;  // per-tile kernel: every item costs a wave its start-up and its ragged end
-    if (const char *env = getenv("PTRT_ITEMS_PER_SLOT")) per_slot = (uint32_t)atoi(env);  // tuning aid
-    sch.wanted_items = ctx->resident_waves * per_slot;
-    if (const char *env = getenv("PTRT_WANTED_ITEMS")) sch.wanted_items = (uint32_t)atoi(env);  // tuning aid
+    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? 44 : 2);  // per-tile kernel: every item costs a wave its start-up and its ragged end
+    sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
-    sch.max_chunk = 0;
-    sch.min_chunk = use_pool ? 8 : 1;
-    if (const char *env = getenv("PTRT_MIN_CHUNK")) sch.min_chunk = (uint32_t)atoi(env);  // tuning aid
-    if (const char *env = getenv("PTRT_MAX_CHUNK")) sch.max_chunk = (uint32_t)atoi(env);  // tuning aid
+    sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
+    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? 8 : 1);
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
@@ -570,22 +573,14 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.next_item = ctx->next_item;
     sch.pool_gstack = ctx->pool_gstack;
     sch.n_cus = ctx->n_cus;
-    sch.pool_groups = 0;
-    if (const char *env = getenv("PTRT_POOL_GROUPS")) sch.pool_groups = (uint32_t)atoi(env);  // tuning aid
-    p.pool_start = 48;
-    if (const char *env = getenv("PTRT_POOL_START")) p.pool_start = (uint32_t)atoi(env);  // tuning aid
-    p.pool_topup = 16;
-    if (const char *env = getenv("PTRT_POOL_TOPUP")) p.pool_topup = (uint32_t)atoi(env);  // tuning aid
-    p.pool_dense = 16;
-    if (const char *env = getenv("PTRT_POOL_DENSE")) p.pool_dense = (uint32_t)atoi(env);  // tuning aid
-    p.pool_shade_dense = 128;
-    if (const char *env = getenv("PTRT_POOL_SHADE_DENSE")) p.pool_shade_dense = (uint32_t)atoi(env);  // tuning aid
-    p.pool_miss_iters = 16;
-    if (const char *env = getenv("PTRT_POOL_MISS_ITERS")) p.pool_miss_iters = (uint32_t)atoi(env);  // tuning aid
-    p.pool_miss_lanes = 48;
-    if (const char *env = getenv("PTRT_POOL_MISS_LANES")) p.pool_miss_lanes = (uint32_t)atoi(env);  // tuning aid
-    p.pool_steps = 8;
-    if (const char *env = getenv("PTRT_POOL_STEPS")) p.pool_steps = (uint32_t)atoi(env);  // tuning aid
+    sch.pool_groups = env_u32("PTRT_POOL_GROUPS", 0);
+    p.pool_start = env_u32("PTRT_POOL_START", 48);
+    p.pool_topup = env_u32("PTRT_POOL_TOPUP", 16);
+    p.pool_dense = env_u32("PTRT_POOL_DENSE", 16);
+    p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", 128);
+    p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", 16);
+    p.pool_miss_lanes = env_u32("PTRT_POOL_MISS_LANES", 48);
+    p.pool_steps = env_u32("PTRT_POOL_STEPS", 8);
     p.max_idle = 1u << 22;
 
     // the per-lane ray counter is 32 bits: bound the frames of one launch
