@@ -1,0 +1,71 @@
+"""The configurations of the headline benchmark at their full sizes, against the CPU oracle: the reference's own
+small case in full (bit-exact), and 1080p frames of the sphere scene and of the 69 k-triangle mesh scene -- single
+dispatches bit-exact, a fused launch long enough to be split into work items equal up to fp32 summation order,
+ray counts exact.  Sized so that the oracle's share stays at a few seconds on 16 host threads."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    same = got.view(np.uint32) == want.view(np.uint32)
+    assert same.all(), f"{what}: {int((~same).sum())} of {got.size} values differ (max abs {np.abs(got - want).max():.3e})"
+
+
+def _config(pt, scenes, name, sky_size):
+    factory, w, h, settings, frames = scenes.CONFIGS[name]
+    return factory(), w, h, settings, frames, scenes.sky_cube_direct(sky_size)
+
+
+def test_cornell_640x360_spp16_in_full(pt, po, scenes):
+    """BASELINE configs[0]: one dispatch of 16 samples per pixel, depth 4."""
+    scene, w, h, st, frames, sky = _config(pt, scenes, "cornell_640x360_d4_spp16", 64)
+    assert (w, h, st.samples_per_pixel, st.depth, frames) == (640, 360, 16, 4, 1)
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV)
+    r.set_sky_cube(sky)
+    r.render(1)
+    want, prim, tt, ost = po.from_scene(scene, w, h, st, sky).render(1, want_aov=True)
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim)
+    _exact(gt, tt, "primary-hit t")
+    _exact(r.read_sum(), want, "radiance")
+    assert r.stats()["rays"] == ost["rays"]
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["three_balls_1080p_d8_spp256", "bunny_1080p_d8_spp256"])
+def test_1080p_frames_match_oracle(pt, po, scenes, name):
+    scene, w, h, st, frames, sky = _config(pt, scenes, name, 256)
+    assert (w, h, st.depth, frames) == (1920, 1080, 8, 256)
+    osc = po.from_scene(scene, w, h, st, sky)
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV)
+    r.set_sky_cube(sky)
+    # two dispatches, frame after frame: the same bits
+    r.render(1)
+    want, prim, tt, ost = osc.render(1, want_aov=True)
+    rays = ost["rays"]
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim)
+    _exact(gt, tt, "primary-hit t")
+    r.render(2)
+    want, _, _, ost = osc.render(2, want)
+    rays += ost["rays"]
+    _exact(r.read_sum(), want, "two 1080p frames")
+    assert r.stats()["rays"] == rays
+    # a fused launch that is planned into work items (>= 16 frames): same samples, sums equal up to their order
+    n = 24
+    r.reset_ready_samples()
+    r.render_frames(100, 1, n)
+    want = np.zeros((h, w, 4), np.float32)
+    rays = 0
+    for f in range(n):
+        want, _, _, ost = osc.render(100 + f, want)
+        rays += ost["rays"]
+    got = r.read_sum()
+    assert r.stats()["rays"] == rays and (got[..., 3] == n).all()
+    np.testing.assert_allclose(got, want, rtol=n * 2.0 ** -23, atol=1e-6)
+    r.close()
