@@ -49,11 +49,11 @@ typedef enum pt_status {
 /* Two implementations of the megakernel give the same image bit for bit (short launches) or up to fp32
    summation order (fused launches of 16 frames or more).  By default the library picks by mesh size. */
 #define PT_FLAG_TILE_KERNEL 8u        /* always the one-wave-per-tile kernel */
-#define PT_FLAG_POOL_KERNEL 16u
+#define PT_FLAG_POOL_KERNEL 16u       /* always the pooled kernel (where it can run: depth >= 1, image <= 65535^2) */
 /* Extension, off by default: triangles shade with the albedo and material of their own records
  * (TriangleBuffer, src/model.rs:66-67, 86-87) instead of the white Lambertian the shader gives every
  * triangle (compute.wgsl:359-367). */
-#define PT_FLAG_TRIANGLE_MATERIALS 32u       /* always the pooled kernel (where it can run: depth >= 1, image <= 65535^2) */
+#define PT_FLAG_TRIANGLE_MATERIALS 32u
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */
 #define PT_PRIM_NONE 0xFFFFFFFFu      /* miss */

@@ -244,3 +244,22 @@ def test_hdr_decode_rejects_bad_files(pt, po):
             pt.decode_hdr(data)
         with pytest.raises(ValueError):
             po.hdr_decode(data)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ptrt.h is the boundary a C, Rust or cgo caller binds: it must compile as strict C99 on its own, and a C
+    program using every entry point must link against the library (nothing is called: no GPU here)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = os.path.join(root, "include", "ptrt.h")
+    names = re.findall(r"^(?:int|int64_t|void|void \*|const char \*)\s*\**(pt_\w+)\(", open(header).read(), re.M)
+    assert len(names) >= 30
+    src = tmp_path / "use_all.c"
+    src.write_text('#include "ptrt.h"\n#include <stdio.h>\nint main(void) {\n  const void *fns[] = {'
+                   + ", ".join(f"(const void *){n}" for n in names)
+                   + '};\n  printf("%d entry points\\n", (int)(sizeof fns / sizeof fns[0]));\n  return 0;\n}\n')
+    lib_dir = os.path.join(root, "path-tracer_amd")
+    exe = tmp_path / "use_all"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), "-L", lib_dir, "-lptrt", "-Wl,-rpath," + lib_dir])
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", header])
