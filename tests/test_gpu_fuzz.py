@@ -64,3 +64,30 @@ def test_random_scene(pt, po, scenes, seed):
     assert same.all(), f"{what}: {int((~same).sum())} of {got.size} sums differ"
     assert r.stats()["rays"] == rays, what
     r.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scene_planned_launch(pt, po, scenes, seed):
+    """Fused launches of 16 frames and more are split into work items by measured cost: same samples and ray
+    counts as the oracle's frame-by-frame sums, equal up to fp32 summation order; a second launch reuses the plan."""
+    rng = np.random.default_rng(5000 + seed)
+    scene = _random_scene(pt, scenes, rng)
+    w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
+    st = pt.Settings(int(rng.integers(1, 3)), int(rng.integers(1, 10)), 1e-4, 1000.0)
+    sky = scenes.sky_cube_direct(8)
+    r = pt.Renderer(scene, w, h, settings=st)
+    r.set_sky_cube(sky)
+    osc = po.from_scene(scene, w, h, st, sky)
+    want = np.zeros((h, w, 4), np.float32)
+    rays, total = 0, 0
+    for t0 in (7, 1000):
+        n = int(rng.integers(16, 48))
+        r.render_frames(t0, 1, n)
+        for f in range(n):
+            want, _, _, ost = osc.render(t0 + f, want)
+            rays += ost["rays"]
+        total += n
+    got = r.read_sum()
+    assert r.stats()["rays"] == rays and (got[..., 3] == total).all()
+    np.testing.assert_allclose(got, want, rtol=total * 2.0 ** -23, atol=1e-6)
+    r.close()
