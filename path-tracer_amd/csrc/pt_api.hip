@@ -551,9 +551,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         PT_HIP(ctx, hipMalloc((void **)&ctx->pool_gstack, pgs));
         ctx->pool_gstack_bytes = pgs;
     }
-    // per-tile kernel: lanes that must wait for shading before the wave runs a shading pass; long walks
-    // (big meshes) favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s)
-    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 64 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48));
+    // Slots that must be ready before a wave runs a shading pass.  Per-tile kernel: long walks (big meshes)
+    // favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s).  Pooled kernel: half a
+    // wave's worth (48 for a wave that is busy walking); waiting for full passes was better only before misses
+    // stayed in registers (bench scene 32.5 vs 31.5 Grays/s, 10 M-triangle field 4.76 vs 4.46).
+    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 32 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48));
 
     PtSchedule sch{};
     sch.cost = ctx->tile_cost;
@@ -577,7 +579,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.pool_start = env_u32("PTRT_POOL_START", 48);
     p.pool_topup = env_u32("PTRT_POOL_TOPUP", 16);
     p.pool_dense = env_u32("PTRT_POOL_DENSE", 16);
-    p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", 128);
+    p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", 48);
     p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", 16);
     p.pool_miss_lanes = env_u32("PTRT_POOL_MISS_LANES", 48);
     p.pool_steps = env_u32("PTRT_POOL_STEPS", 8);

@@ -8,3 +8,5 @@ for v in 32 48; do run PTRT_REFILL_LANES=$v; done
 for v in 64 256; do run PTRT_POOL_SHADE_DENSE=$v; done
 for v in 4 32 64; do run PTRT_POOL_DENSE=$v; done
 for v in 0 128; do run PTRT_POOL_START=$v; done
+for v in 24 32 64; do run PTRT_ITEMS_PER_SLOT=$v; done
+for v in 4 16; do run PTRT_MIN_CHUNK=$v; done
