@@ -576,11 +576,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.pool_gstack = ctx->pool_gstack;
     sch.n_cus = ctx->n_cus;
     sch.pool_groups = env_u32("PTRT_POOL_GROUPS", 0);
-    p.pool_start = env_u32("PTRT_POOL_START", 48);
+    p.pool_start = env_u32("PTRT_POOL_START", 32);
     p.pool_topup = env_u32("PTRT_POOL_TOPUP", 16);
     p.pool_dense = env_u32("PTRT_POOL_DENSE", 16);
     p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", 48);
-    p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", 16);
+    p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", 32);
     p.pool_miss_lanes = env_u32("PTRT_POOL_MISS_LANES", 48);
     p.pool_steps = env_u32("PTRT_POOL_STEPS", 8);
     p.max_idle = 1u << 22;
