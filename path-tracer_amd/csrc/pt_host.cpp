@@ -169,6 +169,7 @@ struct BvhBuilder {
         struct Top {
             PtNode rec;
             int left = -1, right = -1;  // children in `top`, or -1: a subtree for the threads (or a leaf)
+            bool leaf = false;          // its split was tried here and failed: it stays as it is
         };
         std::vector<Top> top;
         top.push_back({root});
@@ -181,7 +182,10 @@ struct BvhBuilder {
             if (top[t].rec.triangle_count < 4096u) break;  // (the largest is small: nothing left worth splitting here)
             open.pop_back();
             PtNode l, r;
-            if (!split(top[t].rec, l, r)) continue;  // stays a leaf; no longer open
+            if (!split(top[t].rec, l, r)) {  // stays a leaf; a second try would permute its triangle range again
+                top[t].leaf = true;
+                continue;
+            }
             top[t].left = (int)top.size();
             top.push_back({l});
             top[t].right = (int)top.size();
@@ -195,7 +199,7 @@ struct BvhBuilder {
         // every top node without children: its subtree, numbered from 1 relative to its root at 0
         std::vector<int> jobs;
         for (size_t t = 0; t < top.size(); t++)
-            if (top[t].left < 0) jobs.push_back((int)t);
+            if (top[t].left < 0 && !top[t].leaf) jobs.push_back((int)t);
         std::sort(jobs.begin(), jobs.end(), [&top](int a, int b) { return top[a].rec.triangle_count > top[b].rec.triangle_count; });
         std::vector<std::vector<PtNode>> sub(top.size());
         std::atomic<size_t> next{0};
@@ -239,6 +243,10 @@ struct BvhBuilder {
                 todo.push_back({top[t].right, li + 1});
                 todo.push_back({top[t].left, li});
             } else {
+                if (top[t].leaf) {
+                    nodes[ni] = top[t].rec;
+                    continue;
+                }
                 moves.push_back({t, used});
                 nodes[ni] = sub[t][0];
                 if (sub[t].size() > 1) nodes[ni].left_child_index += used - 1u;  // an interior root: its children's number

@@ -75,6 +75,43 @@ def test_bvh_builder_threads_give_the_same_tree(pt, po, scenes, monkeypatch):
         assert nodes.tobytes() == want_nodes.tobytes() and np.array_equal(idx, want_idx), threads
 
 
+def test_bvh_builder_threads_with_unsplittable_nodes(pt, po, scenes, monkeypatch):
+    """A big node whose split fails (every centroid on one side) keeps the permutation that one failed
+    attempt leaves behind, whichever thread count builds the tree: 66 000 copies of one triangle, and a mesh with
+    a 40 000-copy clump in it."""
+    one = np.zeros(1, pt.TRIANGLE_DTYPE)
+    one["a"][0], one["b"][0], one["c"][0] = (0, 0, 0), (1, 0, 0), (1, 0.1, 0)  # centroid beyond the middle of its box
+    one["na"][0] = one["nb"][0] = one["nc"][0] = (0, 0, 1)
+    clump = np.repeat(one, 66000)
+    mixed = np.concatenate([scenes.blob_mesh(50), np.repeat(one, 40000)])
+    for tris in (clump, mixed):
+        want_nodes, want_idx = po.bvh_build(tris)
+        for threads in ("1", "4"):
+            monkeypatch.setenv("PTRT_BUILD_THREADS", threads)
+            nodes, idx = pt.bvh_build(tris)
+            assert nodes.tobytes() == want_nodes.tobytes() and np.array_equal(idx, want_idx), threads
+
+
+def test_host_helpers_under_sanitizers(tmp_path):
+    """Damaged .hdr and OBJ files and hostile triangle sets through the host helpers under ASan/UBSan
+    (tests/csrc/host_fuzz.cpp compiles path-tracer_amd/csrc/pt_host.cpp into the driver)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "host_fuzz"
+    built = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-I", os.path.join(root, "include"), os.path.join(root, "tests", "csrc", "host_fuzz.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True)
+    if built.returncode != 0 and "sanitize" in built.stderr and "cannot find" in built.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert built.returncode == 0, built.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    ran = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
+    assert ran.returncode == 0 and ran.stdout.strip().endswith("ok"), ran.stdout[-2000:] + ran.stderr[-4000:]
+
+
 def test_bvh_empty_and_bad_arguments(pt):
     nodes, idx = pt.bvh_build(np.zeros(0, pt.TRIANGLE_DTYPE))
     assert len(nodes) == 0 and len(idx) == 0
