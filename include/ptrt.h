@@ -88,7 +88,8 @@ int pt_set_flags(pt_ctx *ctx, uint32_t flags);
  * tris: n_tris x 112 B, nodes: n_nodes x 32 B, tri_idx: n_idx x u32 (bindings 3, 5, 4 of
  * compute.wgsl:75-77).  Copied; the caller's memory is not referenced afterwards.  The BVH is
  * validated (child/leaf ranges in bounds, children stored after their parent) so that a
- * malformed tree is rejected instead of hanging the GPU.  n_nodes == 0 clears the mesh. */
+ * malformed tree is rejected instead of hanging the GPU; so is a tree deeper than 4096 levels
+ * (PT_ERR_LIMIT: traversal stacks are sized by the depth).  n_nodes == 0 clears the mesh. */
 int pt_set_mesh(pt_ctx *ctx, const void *tris, uint32_t n_tris, const void *nodes, uint32_t n_nodes,
                 const uint32_t *tri_idx, uint32_t n_idx);
 

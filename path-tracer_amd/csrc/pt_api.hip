@@ -349,6 +349,11 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
         return PT_TOKEN_LEAF | i;
     };
 
+    // The traversal stacks are sized by the tree's depth; a degenerate tree (the reference's builder peels a
+    // clump of identical triangles off one at a time) would ask for gigabytes of them.
+    if (max_depth > PT_MAX_BVH_DEPTH)
+        return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: BVH depth %u exceeds %u (the reference shader's own stack holds 15 entries)", max_depth, PT_MAX_BVH_DEPTH);
+
     // Sibling pairs (l, l+1), interleaved component by component so that the two slab tests of a node
     // visit are packed two-wide: {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
     // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}, at the place of nodes l and l+1.

@@ -65,6 +65,7 @@ static_assert(sizeof(PtNode) == 32 && offsetof(PtNode, left_child_index) == 12 &
               "Node layout");
 
 #define PT_MAX_SPHERES 256u
+#define PT_MAX_BVH_DEPTH 4096u  // deepest tree pt_set_mesh accepts (traversal stacks are sized by it)
 
 // ---- node reference ("token") used by the traversal stack ---------------------------
 // bit 31 clear: interior node; the value is the index of its first child (second = +1).

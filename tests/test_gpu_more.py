@@ -237,6 +237,24 @@ def test_display_window_matches_oracle(pt, po, scenes):
     r.close()
 
 
+def test_degenerate_deep_tree_is_refused(pt, scenes):
+    """5000 copies of one triangle whose centroid lies before the middle of its box: the reference's builder peels
+    them off one per level; a tree that deep is refused instead of sizing traversal stacks for it."""
+    one = np.zeros(1, pt.TRIANGLE_DTYPE)
+    one["a"][0], one["b"][0], one["c"][0] = (0, 0, 0), (1, 0, 0), (0, 0.1, 0)
+    one["na"][0] = one["nb"][0] = one["nc"][0] = (0, 0, 1)
+    tris = np.repeat(one, 5000)
+    nodes, idx = pt.bvh_build(tris)
+    assert len(nodes) == 2 * 4999 - 1  # one level per triangle until two are left
+    r = pt.Renderer(scenes.three_balls(), 16, 16, settings=pt.Settings(1, 2, 1e-4, 1000.0))
+    with pytest.raises(pt.PtError) as e:
+        r.set_mesh(tris, nodes, idx)
+    assert e.value.code == -5 and "depth" in str(e.value)  # PT_ERR_LIMIT
+    r.render(1)  # the context is still usable (spheres only)
+    assert r.stats()["rays"] > 0
+    r.close()
+
+
 def test_readouts(pt, scenes):
     scene = scenes.three_balls()
     r = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0))
