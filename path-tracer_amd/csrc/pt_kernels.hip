@@ -982,7 +982,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 {
     using FL = PPFields<GIZMO, SPP1>;
     __shared__ PPShared<FL::COUNT> sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's index, as a scalar: comparisons with it need no lane masks
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const PtDeviceScene &sc = P.sc;
     for (uint32_t i = tid; i < PT_PP_QCAP; i += PT_PP_THREADS) { sh.ready[i] = 0; sh.ready_hit[i] = 0; sh.pending[i] = 0; }
