@@ -879,6 +879,9 @@ struct PPShared {
 // compiler neither caches nor reorders across the fences around them).
 __device__ __forceinline__ uint32_t lds_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Same word read by every lane of the wave: hands the value over as a scalar, so that what is computed from it stays
+// in scalar registers and scalar branches instead of lane masks.
+__device__ __forceinline__ uint32_t lds_load_uniform(uint32_t *p) { return __builtin_amdgcn_readfirstlane(lds_load(p)); }
 
 struct PPStack {
     uint32_t *lds;   // &sh.stack[0][tid]
@@ -1122,11 +1125,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         dg_trips++;
 #endif
         // wave-uniform view of the pool
-        uint32_t n_pend = lds_load(&sh.pend_tail) - lds_load(&sh.pend_head);
+        uint32_t n_pend = lds_load_uniform(&sh.pend_tail) - lds_load_uniform(&sh.pend_head);
         if (n_pend > PT_PP_QCAP) n_pend = 0;
-        uint32_t n_miss = lds_load(&sh.ready_tail) - lds_load(&sh.ready_head);
+        uint32_t n_miss = lds_load_uniform(&sh.ready_tail) - lds_load_uniform(&sh.ready_head);
         if (n_miss > PT_PP_QCAP) n_miss = 0;
-        uint32_t n_hit = lds_load(&sh.hit_tail) - lds_load(&sh.hit_head);
+        uint32_t n_hit = lds_load_uniform(&sh.hit_tail) - lds_load_uniform(&sh.hit_head);
         if (n_hit > PT_PP_QCAP) n_hit = 0;
         const unsigned long long free_mask = __ballot(!wbusy);
         const uint32_t n_free = (uint32_t)__popcll(free_mask);
@@ -1138,11 +1141,14 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         // most walkers and still has room (ties to the lower wave index), so that walks concentrate
         // on few, well-filled waves; the others take rays only when so many wait that the leader
         // cannot hold them.
-        bool leader = true;
+        // (walkers * waves + (waves - 1 - index) orders the waves by walkers, ties to the lower index; a full wave is out)
+        int32_t best_other = -1;
         for (uint32_t o = 0; o < PT_PP_WAVES; o++) {
-            const uint32_t ob = lds_load(&sh.busy[o]);
-            if (o != wv && ob < 64u && (ob > 64u - n_free || (ob == 64u - n_free && o < wv))) leader = false;
+            const uint32_t ob = lds_load_uniform(&sh.busy[o]);
+            const int32_t key = (o != wv && ob < 64u) ? (int32_t)(ob * PT_PP_WAVES + (PT_PP_WAVES - 1u - o)) : -1;
+            best_other = max(best_other, key);
         }
+        const bool leader = best_other < (int32_t)((64u - n_free) * PT_PP_WAVES + (PT_PP_WAVES - 1u - wv));
         if (n_pend != 0u && n_free != 0u &&
             (desperate || (leader ? (n_free >= P.pool_topup || n_pend >= n_free || n_free == 64u) : n_pend >= P.pool_start + 64u))) {
             const uint32_t id = ring_pop(sh.pending, &sh.pend_head, &sh.pend_tail, free_mask, lane, lt_mask);
@@ -1216,9 +1222,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             ring_push3(sh.ready, &sh.ready_tail, fin && !w.rec.hit, sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, sh.pending, &sh.pend_tail, false, wpath, lane,
                        lt_mask);
             if (__ballot(fin)) {
-                n_miss = lds_load(&sh.ready_tail) - lds_load(&sh.ready_head);
+                n_miss = lds_load_uniform(&sh.ready_tail) - lds_load_uniform(&sh.ready_head);
                 if (n_miss > PT_PP_QCAP) n_miss = 0;
-                n_hit = lds_load(&sh.hit_tail) - lds_load(&sh.hit_head);
+                n_hit = lds_load_uniform(&sh.hit_tail) - lds_load_uniform(&sh.hit_head);
                 if (n_hit > PT_PP_QCAP) n_hit = 0;
             }
         }
@@ -1577,7 +1583,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
         }
 
-        if (lds_load(&sh.live) == 0u) break;
+        if (lds_load_uniform(&sh.live) == 0u) break;
         if (did_work) {
             idle = 0;
         } else {
