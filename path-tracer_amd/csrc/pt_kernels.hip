@@ -547,16 +547,21 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
 }
-// The pointers are taken from the kernel argument itself: the compiler knows that those point to
-// global memory, while a pointer rebuilt from plain words would be dereferenced through the slower
-// generic-address path.
+// The pointers used in inner loops are taken from the kernel argument itself: the compiler knows that those
+// point to global memory, while a pointer rebuilt from plain words is dereferenced through the slower
+// generic-address path.  The rarely used ones (primary-hit output) stay rebuilt, so that their kernel-argument
+// values need not live in scalar registers across the persistent loop.
 #define PT_FRESH_PARAMS(L)                                                                                       \
     PtTraceParams L;                                                                                             \
     pt_fresh_params(L);                                                                                          \
     L.sc.spheres = P.sc.spheres; L.sc.nodes = P.sc.nodes; L.sc.node_meta = P.sc.node_meta;                      \
     L.sc.tri_pos = P.sc.tri_pos; L.sc.tri_nrm = P.sc.tri_nrm; L.sc.sky = P.sc.sky;                              \
     L.items = P.items; L.partial = P.partial; L.cost = P.cost; L.accum = P.accum;                               \
-    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t; L.next_item = P.next_item
+    L.next_item = P.next_item
+// (the per-tile kernel keeps few scalars live and is faster with all its pointers taken from the argument)
+#define PT_FRESH_PARAMS_ALL(L) \
+    PT_FRESH_PARAMS(L);        \
+    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t
 
 // ---- the megakernel ---------------------------------------------------------------------
 // GIZMO: some sphere has material 3 (only then is the path's first direction kept);
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #endif
             // (the shading block re-reads the parameter block, so that the walk loop does not have to keep
             // all of it in scalar registers)
-            PT_FRESH_PARAMS(L);
+            PT_FRESH_PARAMS_ALL(L);
             if (mode == M_SHADE) {
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
@@ -1143,6 +1148,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         // cannot hold them.
         // (walkers * waves + (waves - 1 - index) orders the waves by walkers, ties to the lower index; a full wave is out)
         int32_t best_other = -1;
+#pragma nounroll  // (unrolled, the four comparisons with the wave's index are hoisted out of the main loop as lane masks)
         for (uint32_t o = 0; o < PT_PP_WAVES; o++) {
             const uint32_t ob = lds_load_uniform(&sh.busy[o]);
             const int32_t key = (o != wv && ob < 64u) ? (int32_t)(ob * PT_PP_WAVES + (PT_PP_WAVES - 1u - o)) : -1;
@@ -1621,12 +1627,14 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     // a wave that gave up (should never happen) leaves a mark for the host instead of hanging the GPU
     if ((__ballot(wbusy) != 0ull || lds_load(&sh.live) != 0u) && lane == 0) atomicAdd(P.next_item + 1, 1u);
 
+    PtTraceParams LE;  // (re-read: the counters' address is not kept in registers through the loop)
+    pt_fresh_params(LE);
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 1;
     for (int k = 0; k < ncount; k++) {
         if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&P.counters[k], (unsigned long long)s);
+        if (lane == 0 && s) atomicAdd(&LE.counters[k], (unsigned long long)s);
     }
 }
 
