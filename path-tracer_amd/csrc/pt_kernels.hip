@@ -891,7 +891,7 @@ __device__ __forceinline__ uint32_t lds_load_uniform(uint32_t *p) { return __bui
 struct PPStack {
     uint32_t *lds;   // &sh.stack[0][tid]
     uint32_t *spill;
-    size_t pitch;
+    uint32_t pitch;  // threads of the launch (at most 2^18): entry e of this thread is spill[(e - PT_PP_STACK) * pitch]
     __device__ __forceinline__ void push(uint32_t sp, uint32_t v)
     {
         if (sp < PT_PP_STACK) lds[sp * PT_PP_THREADS] = v;
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     }
     __syncthreads();
 
-    PPStack stack{&sh.stack[0][tid], P.gstack ? P.gstack + ((size_t)blockIdx.x * PT_PP_THREADS + tid) : nullptr, (size_t)gridDim.x * PT_PP_THREADS};
+    PPStack stack{&sh.stack[0][tid], P.gstack ? P.gstack + ((size_t)blockIdx.x * PT_PP_THREADS + tid) : nullptr, gridDim.x * PT_PP_THREADS};
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Gives each lane with `need` a job for slot p, in lane order, from the group's open work item
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             did_work = true;
             bool fin = false;
             __builtin_amdgcn_s_setprio(3);  // a walk step is short and waits on memory: let it issue ahead of shading
-            for (uint32_t k = 0; k < P.pool_steps; k++) {
+            for (uint32_t k = 0;; k++) {  // (at least one step: no entry test to hoist)
 #ifdef PT_DIAG
                 dg_steps++;
                 dg_busy += __popcll(__ballot(wbusy));
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         fin = true;
                     }
                 }
-                if (__ballot(wbusy) == 0ull) break;
+                if (__ballot(wbusy) == 0ull || k + 1u >= P.pool_steps) break;
             }
             __builtin_amdgcn_s_setprio(0);
             ring_push3(sh.ready, &sh.ready_tail, fin && !w.rec.hit, sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, sh.pending, &sh.pend_tail, false, wpath, lane,
