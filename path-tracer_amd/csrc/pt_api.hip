@@ -531,15 +531,19 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     p.aov_t = ctx->aov_t;
     p.counters = ctx->counters;
     // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
-    // global memory) and wins when BVH walks are long, i.e. on big meshes; measured on this GPU
-    // (tools/kernel_choice.py) the per-tile kernel is faster up to ~12k triangles and the pooled one from
-    // ~70k on, provided the launch is long enough to fill its path pool (69k triangles: 9.9 vs 18.1 Grays/s
-    // at 32 frames, 25.4 vs 25.4 at 128, 30.0 vs 28.4 at 256), so the switch is triangle count and
-    // launch length.  Flags or PTRT_KERNEL force either;
-    // depth 0 and images wider or taller than 65535 always take the per-tile kernel.
+    // global memory), needs a long launch to fill its path pool, and its spp > 1 variants run at three
+    // waves per SIMD instead of four.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled /
+    // per-tile): 1 spp, 256 frames per launch: 1.06 at 192 triangles, 1.10-1.17 from 768 to 28k, 1.3 at 69k;
+    // 1 spp, 128 frames: 0.87-0.95 up to 3k triangles, 1.0 at 12k-28k, 1.07 at 69k, 1.14 at 10 M; 2 spp:
+    // 0.89 at 3k, 0.95 at 69k, 0.96 at 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and
+    // big meshes in launches of 128 frames or more, any mesh worth the name in launches of 256 or more.
+    // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
+    // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
     const uint32_t launch_frames = ctx->window_size ? 1u : n_frames;  // a display window renders frame by frame
-    bool use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES;
+    bool use_pool = ctx->settings.samples_per_pixel == 1u &&
+                    ((ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
+                     (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES_LONG && launch_frames >= PT_POOL_LONG_FRAMES));
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags

@@ -14,8 +14,13 @@
 #define PT_TRACE_WAVES_PER_EU 5   // register budget of the megakernel: 512 / 5 -> at most 96 VGPRs
 #endif
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
-#define PT_POOL_MIN_TRIANGLES 32768u  // meshes from this size on are rendered by the pooled kernel ...
-#define PT_POOL_MIN_FRAMES 128u       // ... in launches of at least this many frames
+// The pooled kernel takes launches of one sample per pixel and frame on meshes of at least
+// PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
+// PT_POOL_MIN_TRIANGLES_LONG in launches of at least PT_POOL_LONG_FRAMES frames.
+#define PT_POOL_MIN_TRIANGLES 32768u
+#define PT_POOL_MIN_FRAMES 128u
+#define PT_POOL_MIN_TRIANGLES_LONG 512u
+#define PT_POOL_LONG_FRAMES 256u
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
