@@ -533,10 +533,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
     // global memory), needs a long launch to fill its path pool, and its spp > 1 variants run at three
     // waves per SIMD instead of four.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled /
-    // per-tile): 1 spp, 256 frames per launch: 1.06 at 192 triangles, 1.10-1.17 from 768 to 28k, 1.3 at 69k;
-    // 1 spp, 128 frames: 0.87-0.95 up to 3k triangles, 1.0 at 12k-28k, 1.07 at 69k, 1.14 at 10 M; 2 spp:
-    // 0.89 at 3k, 0.95 at 69k, 0.96 at 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and
-    // big meshes in launches of 128 frames or more, any mesh worth the name in launches of 256 or more.
+    // per-tile, best of three launches): 1 spp, 96 frames per launch: 0.89-0.98 up to 3k triangles, 1.1-1.4
+    // from 12k on; 128 frames: 0.92-1.04 up to 3k, 1.06-1.26 from 12k on; 192 frames: 1.03 at 192 triangles,
+    // 1.07-1.16 from 768 to 28k, 1.27 at 69k; 64 frames: a tie at 69k; 2 spp: 0.89 at 3k, 0.95 at 69k, 0.96 at
+    // 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and meshes of some size in launches of 96
+    // frames or more, any mesh worth the name in launches of 192 or more.
     // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
     // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
@@ -564,15 +565,18 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s).  Pooled kernel: half a
     // wave's worth (48 for a wave that is busy walking); waiting for full passes was better only before misses
     // stayed in registers (bench scene 32.5 vs 31.5 Grays/s, 10 M-triangle field 4.76 vs 4.46).
-    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 32 : (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES ? 24 : 48));
+    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 32 : (ctx->n_tri_slots >= PT_TILE_EARLY_SHADE_TRIANGLES ? 24 : 48));
 
     PtSchedule sch{};
     sch.cost = ctx->tile_cost;
     sch.sorted = ctx->tile_sorted;
     sch.tile_items = ctx->tile_items;
     sch.cost_valid = &ctx->cost_valid;
-    // pooled kernel: a pixel's frames run one after the other, so costly tiles need short items
-    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? 44 : 2);  // per-tile kernel: every item costs a wave its start-up and its ragged end
+    // Items per resident wave slot.  Pooled kernel: a pixel's frames run one after the other, so costly tiles need
+    // short items, but every item costs 64 job hand-outs and a row of partial sums: about one item per slot and six
+    // frames of the launch is best (bench scene: 22 at 128 frames, 33 at 192, 36-44 at 256, 64 at 512).  Per-tile
+    // kernel: every item costs a wave its start-up and its ragged end.
+    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_frames / 6u, 6u), 64u) : 2);
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
