@@ -186,7 +186,7 @@ def main():
                        "parallelism": f"sample-split x{world}, one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "pool_kernel for this workload (library default at 1 spp per frame for meshes >= 8192 triangles in launches >= 96 "
+                         "kernel": "pool_kernel for this workload (library default at 1 spp per frame for meshes >= 8192 triangles in launches >= 48 "
                                    "frames and meshes >= 512 triangles in launches >= 192 frames; trace_kernel otherwise), + plan_kernel, "
                                    "accumulate_kernel, and a 4-frame probe launch in the first step",
                          "kernel_ms": k_ms, "flops_per_launch": flops,

@@ -533,11 +533,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
     // global memory), needs a long launch to fill its path pool, and its spp > 1 variants run at three
     // waves per SIMD instead of four.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled /
-    // per-tile, best of three launches): 1 spp, 96 frames per launch: 0.89-0.98 up to 3k triangles, 1.1-1.4
-    // from 12k on; 128 frames: 0.92-1.04 up to 3k, 1.06-1.26 from 12k on; 192 frames: 1.03 at 192 triangles,
-    // 1.07-1.16 from 768 to 28k, 1.27 at 69k; 64 frames: a tie at 69k; 2 spp: 0.89 at 3k, 0.95 at 69k, 0.96 at
-    // 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and meshes of some size in launches of 96
-    // frames or more, any mesh worth the name in launches of 192 or more.
+    // per-tile, best of three launches): 1 spp, 16 frames per launch: 0.8 at every size; 32 frames: 0.8 up to 3k
+    // triangles, 1.0 from 12k on; 64 frames: 0.8 up to 3k, 1.06-1.15 from 12k on; 96-128 frames: 0.9-1.0 up to 3k,
+    // 1.1-1.4 from 12k on; 192 frames: 1.03 at 192 triangles, 1.07-1.16 from 768 to 28k, 1.27 at 69k; 2 spp: 0.89
+    // at 3k, 0.95 at 69k, 0.96 at 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and meshes of
+    // some size in launches of 48 frames or more, any mesh worth the name in launches of 192 or more.
     // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
     // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
@@ -580,7 +580,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
-    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? 8 : 1);
+    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? 4 : 1);
     sch.min_planned_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid

@@ -18,7 +18,7 @@
 // PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
 // PT_POOL_MIN_TRIANGLES_LONG in launches of at least PT_POOL_LONG_FRAMES frames.
 #define PT_POOL_MIN_TRIANGLES 8192u
-#define PT_POOL_MIN_FRAMES 96u
+#define PT_POOL_MIN_FRAMES 48u
 #define PT_POOL_MIN_TRIANGLES_LONG 512u
 #define PT_POOL_LONG_FRAMES 192u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
