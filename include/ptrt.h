@@ -47,7 +47,8 @@ typedef enum pt_status {
 #define PT_FLAG_AOV 2u                /* record the primary hit of each pixel's first sample */
 #define PT_FLAG_DETAILED_STATS 4u     /* count node steps / triangle tests too (slower kernel) */
 /* Two implementations of the megakernel give the same image bit for bit (short launches) or up to fp32
-   summation order (fused launches of 16 frames or more).  By default the library picks by mesh size. */
+   summation order (fused launches of 16 frames or more).  By default the library picks by mesh size,
+   samples per frame and launch length (the pooled kernel for long 1-spp launches on meshes). */
 #define PT_FLAG_TILE_KERNEL 8u        /* always the one-wave-per-tile kernel */
 #define PT_FLAG_POOL_KERNEL 16u       /* always the pooled kernel (where it can run: depth >= 1, image <= 65535^2) */
 /* Extension, off by default: triangles shade with the albedo and material of their own records
