@@ -115,11 +115,11 @@ int pt_set_settings(pt_ctx *ctx, const void *settings16);
  * goes up by one. */
 int pt_render(pt_ctx *ctx, uint32_t time);
 /* n_frames dispatch-equivalents in one launch: frame i uses time0 + i*stride; lanes start their
- * next frame as soon as their path ends.  Launches of fewer than 16 frames add frame after frame
- * onto the sums and are bit-identical to n_frames pt_render calls (and no faster per frame: a
- * pixel's frames run one after the other).  Launches of 16 frames or more are split into work
- * items by measured cost and summed per item: same samples, sums equal up to fp32 summation
- * order, and several times the throughput (1080p bench scene: 0.7 ms per frame in a 15-frame
+ * next frame as soon as their path ends.  Launches of fewer than 16 frames are bit-identical to
+ * n_frames pt_render calls (every frame is summed on its own and the frames are added in order).
+ * Launches of 16 frames or more are split into work items of several frames by measured cost
+ * and summed per item: same samples, sums equal up to fp32 summation order, and several times
+ * the throughput (1080p bench scene: 1.06 ms for one frame, 0.55 ms per frame in a 15-frame
  * launch, 0.2 ms in a 16-frame one, 0.09 ms from 192 frames on). */
 int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames);
 /* ProgressiveRendering::reset_ready_samples (renderer.rs:635-637): clears the accumulation. */

@@ -581,7 +581,11 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
     sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? 4 : 1);
-    sch.min_planned_frames = 16;
+    // Launches of 2..15 frames: one work item per tile AND frame, the items' single-frame sums added in frame order,
+    // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
+    // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).
+    sch.min_planned_frames = 2;
+    const uint32_t regroup_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
     sch.use_pool = use_pool;
@@ -645,6 +649,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         p.time0 = time0 + done * stride;
         p.n_frames = batch;
         uint32_t blocks = ctx->n_tiles;
+        if (batch < regroup_frames && !getenv("PTRT_MAX_CHUNK")) {
+            sch.max_chunk = 1;
+            sch.min_chunk = 1;
+        }
         if (batch >= sch.min_planned_frames) {
             const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, sch);
             blocks = std::max(blocks, cap);
