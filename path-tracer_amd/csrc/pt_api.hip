@@ -649,12 +649,17 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         p.time0 = time0 + done * stride;
         p.n_frames = batch;
         uint32_t blocks = ctx->n_tiles;
+        PtSchedule bs = sch;  // this batch's schedule
         if (batch < regroup_frames && !getenv("PTRT_MAX_CHUNK")) {
-            sch.max_chunk = 1;
-            sch.min_chunk = 1;
+            bs.max_chunk = 1;
+            bs.min_chunk = 1;
+            // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: not beyond 2 GiB
+            const uint64_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
+            const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->bvh_depth));
+            if (bytes > (2ull << 30)) bs.min_planned_frames = regroup_frames;  // frame after frame, one item per tile
         }
-        if (batch >= sch.min_planned_frames) {
-            const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, sch);
+        if (batch >= bs.min_planned_frames) {
+            const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
             blocks = std::max(blocks, cap);
             if (cap > ctx->item_cap) {
                 PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -666,9 +671,9 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
                 ctx->item_cap = cap;
             }
         }
-        sch.items = ctx->items;
-        sch.partial = ctx->partial;
-        sch.item_cap = ctx->item_cap;
+        bs.items = ctx->items;
+        bs.partial = ctx->partial;
+        bs.item_cap = ctx->item_cap;
         // spill space for traversal stacks deeper than the per-tile kernel keeps in LDS
         const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->bvh_depth);
         if (gs) {
@@ -678,7 +683,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         p.gstack = ctx->gstack;
         p.gstack_cap = gs ? ctx->bvh_depth : 0;
         p.gstack_blocks = gs ? blocks : 0;
-        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
+        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
         done += batch;
         ctx->frames += batch;
         ctx->paths += (uint64_t)p.cols * p.rows * batch * ctx->settings.samples_per_pixel;
