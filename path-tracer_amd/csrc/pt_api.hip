@@ -231,7 +231,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->accum_owned, n * sizeof(float4)), "accumulation buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_prim, n * sizeof(uint32_t)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
-    if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_NUM_COUNTERS * sizeof(unsigned long long)), "counters");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->counters, PT_COUNTER_STRIPES * PT_COUNTER_PITCH * sizeof(unsigned long long)), "counters");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->spheres, 3 * PT_MAX_SPHERES * sizeof(float4)), "sphere buffer");
     const size_t n_tiles = pt_trace_num_tiles(width, height);
     ctx->n_tiles = (uint32_t)n_tiles;
@@ -252,7 +252,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     if (rc == PT_OK) step(hipMemset(ctx->accum_owned, 0, n * sizeof(float4)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_prim, 0xFF, n * sizeof(uint32_t)), "clear");
     if (rc == PT_OK) step(hipMemset(ctx->aov_t, 0, n * sizeof(float)), "clear");
-    if (rc == PT_OK) step(hipMemset(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long)), "clear");
+    if (rc == PT_OK) step(hipMemset(ctx->counters, 0, PT_COUNTER_STRIPES * PT_COUNTER_PITCH * sizeof(unsigned long long)), "clear");
     if (rc != PT_OK) {
         pt_destroy(ctx);
         return rc;
@@ -699,7 +699,7 @@ int pt_reset(pt_ctx *ctx)
     PT_ENTER(ctx);
     const size_t n = (size_t)ctx->width * ctx->height;
     PT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, n * sizeof(float4), ctx->stream));
-    PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, PT_COUNTER_STRIPES * PT_COUNTER_PITCH * sizeof(unsigned long long), ctx->stream));
     ctx->frames = 0;
     ctx->paths = 0;
     if (ctx->window_size) ctx->ready_samples = 1;  // reset_ready_samples, renderer.rs:635-637 (the textures keep their contents)
@@ -825,9 +825,13 @@ int pt_stats(pt_ctx *ctx, pt_stats_t *out)
 {
     PT_ENTER(ctx);
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_stats: null output");
-    unsigned long long c[PT_NUM_COUNTERS];
+    static_assert(PT_COUNTER_PITCH >= PT_NUM_COUNTERS, "a stripe holds every counter");
+    std::vector<unsigned long long> stripes(PT_COUNTER_STRIPES * PT_COUNTER_PITCH);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof c, hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(stripes.data(), ctx->counters, stripes.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long c[PT_NUM_COUNTERS] = {};
+    for (uint32_t s = 0; s < PT_COUNTER_STRIPES; s++)
+        for (uint32_t k = 0; k < PT_NUM_COUNTERS; k++) c[k] += stripes[s * PT_COUNTER_PITCH + k];
     out->rays = c[0];
     out->paths = ctx->paths;
     out->interior = c[2];

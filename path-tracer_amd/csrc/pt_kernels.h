@@ -16,6 +16,11 @@
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
 // The pooled kernel takes launches of one sample per pixel and frame on meshes of at least
 // PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
+// Every wave ends with one atomic add per counter.  A single-frame 1080p launch is 32 400 waves: on one address
+// those atomics alone took 0.39 ms (they serialise in L2), so the counters are striped over 256 cache lines and
+// summed by the host.
+#define PT_COUNTER_STRIPES 256u
+#define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
 // PT_POOL_MIN_TRIANGLES_LONG in launches of at least PT_POOL_LONG_FRAMES frames.
 #define PT_POOL_MIN_TRIANGLES 8192u
 #define PT_POOL_MIN_FRAMES 48u
@@ -61,7 +66,7 @@ struct PtTraceParams {
     float4 *accum;
     uint32_t *aov_prim;  // may be null
     float *aov_t;
-    unsigned long long *counters;  // PT_NUM_COUNTERS
+    unsigned long long *counters;  // PT_COUNTER_STRIPES x PT_COUNTER_PITCH: a workgroup adds to stripe blockIdx.x % PT_COUNTER_STRIPES
     uint32_t *gstack;              // global-memory traversal stack (deep trees only)
     uint32_t gstack_cap;           // deepest stack the buffer is sized for
     uint32_t gstack_blocks;        // workgroups (of the per-tile kernel) the buffer has columns for

@@ -786,7 +786,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
     for (int k = 0; k < ncount; k++) {
         if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&P.counters[k], (unsigned long long)s);
+        if (lane == 0 && s) atomicAdd(&P.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH + k], (unsigned long long)s);
     }
 }
 
@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     for (int k = 0; k < ncount; k++) {
         if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&LE.counters[k], (unsigned long long)s);
+        if (lane == 0 && s) atomicAdd(&LE.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH + k], (unsigned long long)s);
     }
 }
 
