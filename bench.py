@@ -187,8 +187,9 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "pool_kernel for this workload (library default at 1 spp per frame for meshes >= 8192 triangles in launches >= 48 "
-                                   "frames and meshes >= 512 triangles in launches >= 192 frames; trace_kernel otherwise), + plan_kernel, "
-                                   "accumulate_kernel, and a 4-frame probe launch in the first step",
+                                   "frames and meshes >= 512 triangles in launches >= 192 frames; trace_kernel otherwise), + accumulate_kernel; plan_kernel and the per-tile cost "
+                                   "measurement run in the first two launches of a configuration (warm-up), identical launches then reuse the "
+                                   "work-item table; a 4-frame probe launch in the very first step",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_GBps": abytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,

@@ -76,6 +76,21 @@ struct pt_ctx {
 
     uint64_t frames = 0;
 
+    // The plan (item table) of the last planned launch, and what it was made for: an identical launch runs it
+    // again instead of planning anew (nothing that decides a tile's cost has changed).
+    uint64_t scene_generation = 0;  // bumped by everything that can change costs or the plan's buffers
+    struct PlanKey {
+        uint64_t generation = ~0ull;
+        uint32_t n_frames = 0, wanted_items = 0, max_chunk = 0, min_chunk = 0;
+        bool use_pool = false;
+        bool operator==(const PlanKey &o) const
+        {
+            return generation == o.generation && n_frames == o.n_frames && wanted_items == o.wanted_items && max_chunk == o.max_chunk &&
+                   min_chunk == o.min_chunk && use_pool == o.use_pool;
+        }
+    } plan_key;
+    uint32_t plans_for_key = 0;  // plans made in a row for plan_key (the second one rests on a full measurement)
+
     // ProgressiveRendering (renderer.rs:613-646) when pt_set_window has enabled it
     uint32_t window_size = 0;       // sample_size; 0: off
     uint32_t ready_samples = 0;     // renderer.rs:422
@@ -300,6 +315,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
 int pt_set_flags(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
+    ctx->scene_generation++;  // a plan made before this call is not run again
     if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
@@ -308,6 +324,7 @@ int pt_set_flags(pt_ctx *ctx, uint32_t flags)
 int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
 {
     PT_ENTER(ctx);
+    ctx->scene_generation++;  // a plan made before this call is not run again
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // kernels in flight may still read the old mesh
     if (n_nodes == 0) {
         free_mesh(ctx);
@@ -467,6 +484,7 @@ int pt_read_sky_cube(pt_ctx *ctx, float *out)
 int pt_set_camera(pt_ctx *ctx, const void *camera64)
 {
     PT_ENTER(ctx);
+    ctx->scene_generation++;  // a plan made before this call is not run again
     if (!camera64) return fail(ctx, PT_ERR_INVALID, "pt_set_camera: null pointer");
     std::memcpy(&ctx->camera, camera64, sizeof(PtCamera));
     ctx->have_camera = true;
@@ -476,6 +494,7 @@ int pt_set_camera(pt_ctx *ctx, const void *camera64)
 int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
 {
     PT_ENTER(ctx);
+    ctx->scene_generation++;  // a plan made before this call is not run again
     if (!sphere_data8208) return fail(ctx, PT_ERR_INVALID, "pt_set_spheres: null pointer");
     const PtSphereData *sd = static_cast<const PtSphereData *>(sphere_data8208);
     // the storage buffer holds 256 spheres; a larger count would read past it
@@ -498,6 +517,7 @@ int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
 int pt_set_settings(pt_ctx *ctx, const void *settings16)
 {
     PT_ENTER(ctx);
+    ctx->scene_generation++;  // a plan made before this call is not run again
     if (!settings16) return fail(ctx, PT_ERR_INVALID, "pt_set_settings: null pointer");
     std::memcpy(&ctx->settings, settings16, sizeof(PtSettings));
     return PT_OK;
@@ -669,6 +689,21 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
                 PT_HIP(ctx, hipMalloc((void **)&ctx->items, (size_t)cap * sizeof(uint4)));
                 PT_HIP(ctx, hipMalloc((void **)&ctx->partial, (size_t)cap * 64u * sizeof(float4)));
                 ctx->item_cap = cap;
+                ctx->scene_generation++;  // the old plan went with the old table
+            }
+            pt_ctx::PlanKey key;
+            key.generation = ctx->scene_generation;
+            key.n_frames = batch;
+            key.wanted_items = bs.wanted_items;
+            key.max_chunk = bs.max_chunk;
+            key.min_chunk = bs.min_chunk;
+            key.use_pool = use_pool;
+            if (key == ctx->plan_key) {
+                bs.reuse_plan = ctx->plans_for_key >= 2 && ctx->cost_valid && !getenv("PTRT_ALWAYS_PLAN");
+                if (!bs.reuse_plan) ctx->plans_for_key++;
+            } else {
+                ctx->plan_key = key;
+                ctx->plans_for_key = 1;
             }
         }
         bs.items = ctx->items;

@@ -14,13 +14,13 @@
 #define PT_TRACE_WAVES_PER_EU 5   // register budget of the megakernel: 512 / 5 -> at most 96 VGPRs
 #endif
 #define PT_LDS_STACK 24     // traversal stack entries per lane kept in LDS (6 KiB per wave)
-// The pooled kernel takes launches of one sample per pixel and frame on meshes of at least
-// PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
 // Every wave ends with one atomic add per counter.  A single-frame 1080p launch is 32 400 waves: on one address
 // those atomics alone took 0.39 ms (they serialise in L2), so the counters are striped over 256 cache lines and
 // summed by the host.
 #define PT_COUNTER_STRIPES 256u
 #define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
+// The pooled kernel takes launches of one sample per pixel and frame on meshes of at least
+// PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
 // PT_POOL_MIN_TRIANGLES_LONG in launches of at least PT_POOL_LONG_FRAMES frames.
 #define PT_POOL_MIN_TRIANGLES 8192u
 #define PT_POOL_MIN_FRAMES 48u
@@ -103,6 +103,7 @@ struct PtSchedule {
     uint32_t *pool_gstack;        // pt_pool_gstack_bytes() of spill space, null if the tree is shallow enough
     uint32_t n_cus;               // compute units of the device
     uint32_t pool_groups;         // workgroups to launch; 0 = as many as are resident at once
+    bool reuse_plan;              // the item table, tile table and buffers still hold the plan of an identical launch: run it again
 };
 
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).

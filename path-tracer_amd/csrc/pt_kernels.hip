@@ -1992,12 +1992,14 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
     if (cap > sch.item_cap || (spills && p.gstack_blocks < cap)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk, sch.min_chunk,
-                       sch.items, cap, sch.tile_items, sch.sorted);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (!sch.reuse_plan) {
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk,
+                           sch.min_chunk, sch.items, cap, sch.tile_items, sch.sorted);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
+    }
     p.items = sch.items;
     p.partial = sch.partial;
-    p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
     e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
