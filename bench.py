@@ -74,8 +74,8 @@ def cpu_baseline(pt, scenes, scene, w, h, settings, sky_cube, budget_s: float = 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="bunny_1080p_d8_spp256")
     ap.add_argument("--frames", type=int, default=0, help="override frames per step (default: the config's spp)")
     ap.add_argument("--sky-size", type=int, default=4096)
