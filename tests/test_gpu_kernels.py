@@ -111,3 +111,51 @@ def test_automatic_choice_by_mesh_size(pt, scenes):
     auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 130)])
     forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_POOL_KERNEL, [(1, 1, 130)])
     assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]
+
+
+@pytest.mark.parametrize("flag", ["PT_FLAG_POOL_KERNEL", "PT_FLAG_TILE_KERNEL"])
+def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
+    """From the third identical launch on the work-item table of the previous launch is run again (no planning, no
+    cost measurement); setting anything on the context ends that.  Every launch must still trace every sample: ray
+    counts and frame counts exact, sums equal to the oracle's up to summation order, and two contexts fed the same
+    call sequence agree bit for bit."""
+    scene = scenes.bunny(n=12)
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(1, 6, 1e-4, 1000.0)
+    w, h, n = 120, 72, 20
+    osc = po.from_scene(scene, w, h, st, sky)
+    want = np.zeros((h, w, 4), np.float32)
+    rays = 0
+
+    def run(r):
+        for k in range(5):              # launches 3..5 reuse the plan of launch 2
+            r.render_frames(1 + k * n, 1, n)
+        moved = pt.Scene(scene.spheres, scene.triangles, pt.Camera.from_yaw_pitch((0.8, 1.1, 4.2), -92.0, -3.0))
+        r.update_scene(moved)           # new camera: the old plan must not be run again blindly (it would still be correct)
+        for k in range(3):
+            r.render_frames(1000 + k * n, 1, n)
+        return r.read_sum().copy(), r.stats()
+
+    def make():
+        r = pt.Renderer(scene, w, h, settings=st, flags=getattr(pt, flag))
+        r.set_sky_cube(sky)
+        return r
+
+    r1, r2 = make(), make()
+    got, stats = run(r1)
+    got2, stats2 = run(r2)
+    r1.close()
+    r2.close()
+    assert np.array_equal(got.view(np.uint32), got2.view(np.uint32)) and stats == stats2
+    for k in range(5):
+        for f in range(n):
+            want, _, _, ost = osc.render(1 + k * n + f, want)
+            rays += ost["rays"]
+    moved = pt.Scene(scene.spheres, scene.triangles, pt.Camera.from_yaw_pitch((0.8, 1.1, 4.2), -92.0, -3.0))
+    osc2 = po.from_scene(moved, w, h, st, sky)
+    for k in range(3):
+        for f in range(n):
+            want, _, _, ost = osc2.render(1000 + k * n + f, want)
+            rays += ost["rays"]
+    assert stats["rays"] == rays and stats["frames"] == 8 * n and (got[..., 3] == 8 * n).all()
+    np.testing.assert_allclose(got, want, rtol=8 * n * 2.0 ** -23, atol=1e-6)
