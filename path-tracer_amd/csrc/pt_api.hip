@@ -604,7 +604,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // Launches of 2..15 frames: one work item per tile AND frame, the items' single-frame sums added in frame order,
     // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
     // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).
-    sch.min_planned_frames = 2;
+    sch.min_planned_frames = env_u32("PTRT_MIN_PLANNED", 2);
     const uint32_t regroup_frames = 16;
     sch.probe_frames = 4;
     if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
