@@ -556,15 +556,30 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // per-tile, best of three launches): 1 spp, 16 frames per launch: 0.8 at every size; 32 frames: 0.8 up to 3k
     // triangles, 1.0 from 12k on; 64 frames: 0.8 up to 3k, 1.06-1.15 from 12k on; 96-128 frames: 0.9-1.0 up to 3k,
     // 1.1-1.4 from 12k on; 192 frames: 1.03 at 192 triangles, 1.07-1.16 from 768 to 28k, 1.27 at 69k; 2 spp: 0.89
-    // at 3k, 0.95 at 69k, 0.96 at 10 M; no triangles at all: 0.73.  Hence: one sample per frame, and meshes of
-    // some size in launches of 48 frames or more, any mesh worth the name in launches of 192 or more.
+    // at 3k, 0.95 at 69k, 0.96 at 10 M with 320 path slots per workgroup; no triangles at all: 0.73.  Hence, at one
+    // sample per frame: meshes of some size in launches of 48 frames or more, any mesh worth the name in launches of
+    // 192 or more.
     // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
     // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
     const uint32_t launch_frames = ctx->window_size ? 1u : n_frames;  // a display window renders frame by frame
-    bool use_pool = ctx->settings.samples_per_pixel == 1u &&
-                    ((ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
-                     (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES_LONG && launch_frames >= PT_POOL_LONG_FRAMES));
+    // Several samples per pixel and frame (256 path slots per workgroup instead of 320, so that four workgroups
+    // still share a CU; work items sized by samples): a frame of n samples counts as n frames, but launches of 2 to
+    // 15 frames (one item per tile and frame) stay with the per-tile kernel.  Measured the same way, 2 to 16 spp:
+    // 48 samples or more per launch in 16 frames or more: 1.05-1.18 from 8.7k triangles on; 192 samples or more:
+    // 1.04-1.06 at 3k, 0.83-0.90 at 768; one frame of 64 or 256 samples: 1.08-1.17 from 8.7k on, 0.97-1.02 below;
+    // 4 frames of 16 samples: 0.69-0.94; 8 frames of 8: 0.88-1.02.
+    const uint32_t spp_now = std::max(ctx->settings.samples_per_pixel, 1u);
+    const uint64_t samples_now = (uint64_t)launch_frames * spp_now;
+    bool use_pool;
+    if (spp_now == 1u)
+        use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
+                   (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES_LONG && launch_frames >= PT_POOL_LONG_FRAMES);
+    else
+        use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && samples_now >= PT_POOL_MIN_FRAMES &&
+                    (launch_frames == 1u || launch_frames >= PT_POOL_MULTI_MIN_FRAMES)) ||
+                   (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES_LONG && samples_now >= PT_POOL_LONG_FRAMES &&
+                    launch_frames >= PT_POOL_MULTI_MIN_FRAMES);
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags
@@ -596,11 +611,14 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // short items, but every item costs 64 job hand-outs and a row of partial sums: about one item per slot and six
     // frames of the launch is best (bench scene: 22 at 128 frames, 33 at 192, 36-44 at 256, 64 at 512).  Per-tile
     // kernel: every item costs a wave its start-up and its ragged end.
-    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_frames / 6u, 6u), 64u) : 2);
+    // A frame of several samples per pixel counts as that many frames here.
+    const uint32_t spp = std::max(ctx->settings.samples_per_pixel, 1u);
+    const uint32_t launch_samples = (uint32_t)std::min<uint64_t>((uint64_t)launch_frames * spp, 1u << 20);
+    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_samples / 6u, 6u), 64u) : 2);
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
-    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? 4 : 1);
+    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? std::max(4u / spp, 1u) : 1);
     // Launches of 2..15 frames: one work item per tile AND frame, the items' single-frame sums added in frame order,
     // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
     // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).

@@ -19,13 +19,17 @@
 // summed by the host.
 #define PT_COUNTER_STRIPES 256u
 #define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
-// The pooled kernel takes launches of one sample per pixel and frame on meshes of at least
-// PT_POOL_MIN_TRIANGLES in launches of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
-// PT_POOL_MIN_TRIANGLES_LONG in launches of at least PT_POOL_LONG_FRAMES frames.
+// At one sample per pixel and frame the pooled kernel takes launches on meshes of at least
+// PT_POOL_MIN_TRIANGLES of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
+// PT_POOL_MIN_TRIANGLES_LONG of at least PT_POOL_LONG_FRAMES frames.
 #define PT_POOL_MIN_TRIANGLES 8192u
 #define PT_POOL_MIN_FRAMES 48u
 #define PT_POOL_MIN_TRIANGLES_LONG 512u
 #define PT_POOL_LONG_FRAMES 192u
+// With several samples per pixel and frame the same rule counts samples per launch instead of frames, for launches
+// of one frame or of at least PT_POOL_MULTI_MIN_FRAMES, and asks PT_POOL_MULTI_MIN_TRIANGLES_LONG of a long launch.
+#define PT_POOL_MULTI_MIN_FRAMES 16u
+#define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 

@@ -822,9 +822,11 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #endif
 #define PT_PP_THREADS (64 * PT_PP_WAVES)
 #ifndef PT_PP_PATHS
-#define PT_PP_PATHS 320
+#define PT_PP_PATHS 320        // path slots of the plain variant (21 words per slot: four workgroups per CU)
 #endif
-#define PT_PP_SEED (PT_PP_PATHS / PT_PP_WAVES)  // slots each wave gives their first job
+#ifndef PT_PP_PATHS_WIDE
+#define PT_PP_PATHS_WIDE 256   // ... of the variants with wider slots, so that four workgroups per CU still fit
+#endif
 #ifndef PT_PP_QCAP
 #define PT_PP_QCAP 512   // ring capacity: a power of two >= PT_PP_PATHS
 #endif
@@ -836,6 +838,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #define PT_PP_WAVES_PER_EU 4
 #endif
 static_assert(PT_PP_PATHS % PT_PP_WAVES == 0 && PT_PP_PATHS <= PT_PP_QCAP && (PT_PP_QCAP & (PT_PP_QCAP - 1)) == 0, "pool geometry");
+static_assert(PT_PP_PATHS_WIDE % PT_PP_WAVES == 0 && PT_PP_PATHS_WIDE <= PT_PP_PATHS, "pool geometry");
 
 enum : uint32_t {
     F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,  // the path's current ray
@@ -855,6 +858,11 @@ struct PPFields {
     static constexpr uint32_t IDIR = F_BASE + (SPP1 ? 0u : 7u);  // first direction (3) + bounce limit, only with a gizmo sphere
     static constexpr uint32_t LIMIT = IDIR + 3u;
     static constexpr uint32_t COUNT = IDIR + (GIZMO ? 4u : 0u);
+    // Path slots per workgroup.  160 KiB of LDS hold four workgroups of 320 plain slots (21 words); with the 7 words
+    // of spp > 1 or the 4 of a gizmo sphere only three such groups fit, so those variants take 256 slots and keep
+    // four groups (and four waves per SIMD); with both extensions three groups of 320 are the better fit.
+    static constexpr uint32_t PATHS = (GIZMO != !SPP1) ? (uint32_t)PT_PP_PATHS_WIDE : (uint32_t)PT_PP_PATHS;
+    static constexpr uint32_t SEED = PATHS / PT_PP_WAVES;  // slots each wave gives their first job
 };
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
@@ -863,9 +871,9 @@ typedef uint16_t pp_entry;
 __device__ __forceinline__ uint32_t ring_load(pp_entry *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ring_store(pp_entry *p, uint32_t v) { __hip_atomic_store(p, (pp_entry)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <uint32_t NF>
+template <uint32_t NF, uint32_t PATHS>
 struct PPShared {
-    uint32_t st[NF][PT_PP_PATHS];
+    uint32_t st[NF][PATHS];
     uint32_t stack[PT_PP_STACK][PT_PP_THREADS];
     pp_entry ready[PT_PP_QCAP];     // READY, ray missed everything (or no ray yet): sky, next path
     pp_entry ready_hit[PT_PP_QCAP]; // READY, ray hit something: material, bounce
@@ -989,7 +997,7 @@ template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
 {
     using FL = PPFields<GIZMO, SPP1>;
-    __shared__ PPShared<FL::COUNT> sh;
+    __shared__ PPShared<FL::COUNT, FL::PATHS> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's index, as a scalar: comparisons with it need no lane masks
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     if (tid == 0) {
         sh.ready_head = sh.ready_tail = sh.hit_head = sh.hit_tail = sh.pend_head = sh.pend_tail = 0;
         for (uint32_t i = 0; i < PT_PP_WAVES; i++) sh.busy[i] = 0;
-        sh.live = PT_PP_PATHS;
+        sh.live = FL::PATHS;
         sh.job_word = 64u;
         sh.job_lock = 0;
         sh.no_more = 0;
@@ -1087,9 +1095,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     };
 
     // every wave gives its share of the slots their first job
-    for (uint32_t base = 0; base < PT_PP_SEED; base += 64u) {
-        const bool need = base + lane < PT_PP_SEED;
-        const uint32_t p = wv * PT_PP_SEED + base + lane;
+    for (uint32_t base = 0; base < FL::SEED; base += 64u) {
+        const bool need = base + lane < FL::SEED;
+        const uint32_t p = wv * FL::SEED + base + lane;
         const bool got = assign_jobs(need, p);
         ring_push(sh.ready, &sh.ready_tail, got, p, lane, lt_mask);
         const uint32_t n_dead = (uint32_t)__popcll(__ballot(need && !got));

@@ -111,6 +111,20 @@ def test_automatic_choice_by_mesh_size(pt, scenes):
     auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 130)])
     forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_POOL_KERNEL, [(1, 1, 130)])
     assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]
+    # several samples per frame count as that many frames: one frame of 50 samples goes to the pooled kernel too
+    # (a single frame is summed in sample order by both kernels: same bits), and so do 16 frames of 3
+    st = pt.Settings(50, 4, 1e-4, 1000.0)
+    auto = _render(pt, scene, 96, 54, st, sky, 0, [7])
+    for flag in (pt.PT_FLAG_POOL_KERNEL, pt.PT_FLAG_TILE_KERNEL):
+        forced = _render(pt, scene, 96, 54, st, sky, flag, [7])
+        assert np.array_equal(auto[0].view(np.uint32), forced[0].view(np.uint32)) and auto[3] == forced[3]
+    st = pt.Settings(3, 4, 1e-4, 1000.0)
+    auto = _render(pt, scene, 96, 54, st, sky, 0, [(1, 1, 16)])
+    forced = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_POOL_KERNEL, [(1, 1, 16)])
+    tile = _render(pt, scene, 96, 54, st, sky, pt.PT_FLAG_TILE_KERNEL, [(1, 1, 16)])
+    assert auto[3] == forced[3] == tile[3] and np.array_equal(auto[1], tile[1])
+    np.testing.assert_allclose(auto[0], forced[0], rtol=16 * 2.0 ** -23, atol=1e-6)
+    np.testing.assert_allclose(auto[0], tile[0], rtol=16 * 2.0 ** -23, atol=1e-6)
 
 
 @pytest.mark.parametrize("flag", ["PT_FLAG_POOL_KERNEL", "PT_FLAG_TILE_KERNEL"])
