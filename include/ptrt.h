@@ -48,7 +48,7 @@ typedef enum pt_status {
 #define PT_FLAG_DETAILED_STATS 4u     /* count node steps / triangle tests too (slower kernel) */
 /* Two implementations of the megakernel give the same image bit for bit (short launches) or up to fp32
    summation order (fused launches of 16 frames or more).  By default the library picks by mesh size,
-   samples per frame and launch length (the pooled kernel for long 1-spp launches on meshes). */
+   samples per frame and launch length (the pooled kernel for launches of many samples on meshes). */
 #define PT_FLAG_TILE_KERNEL 8u        /* always the one-wave-per-tile kernel */
 #define PT_FLAG_POOL_KERNEL 16u       /* always the pooled kernel (where it can run: depth >= 1, image <= 65535^2) */
 /* Extension, off by default: triangles shade with the albedo and material of their own records
