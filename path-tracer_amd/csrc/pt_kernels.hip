@@ -2010,6 +2010,7 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     p.partial = sch.partial;
     e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
     if (e != hipSuccess) return e;
+    if (p.cols == 0 || p.rows == 0) return hipSuccess;  // image smaller than one 16x16 group under PT_FLAG_REFERENCE_DISPATCH: no pixel is rendered
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
                        sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
     return hipGetLastError();

@@ -1,10 +1,13 @@
 """Seeded random scenes through both megakernels against the CPU oracle: triangle soups with random
 materials, random sphere sets (all four materials, spheres inside spheres), random cameras, odd image sizes, random
 spp/depth, single dispatches and short fused launches.  Everything must agree bit for bit, ray counts included."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+EXTRA = int(os.environ.get("PTRT_FUZZ_EXTRA", "0"))  # more seeds for a one-off soak, e.g. after touching a megakernel
 
 
 def _random_scene(pt, scenes, rng):
@@ -32,7 +35,7 @@ def _random_scene(pt, scenes, rng):
     return pt.Scene(spheres, triangles, cam)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 + EXTRA))
 def test_random_scene(pt, po, scenes, seed):
     rng = np.random.default_rng(1000 + seed)
     scene = _random_scene(pt, scenes, rng)
@@ -66,7 +69,7 @@ def test_random_scene(pt, po, scenes, seed):
     r.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + EXTRA))
 def test_random_scene_planned_launch(pt, po, scenes, seed):
     """Fused launches of 16 frames and more are split into work items by measured cost: same samples and ray
     counts as the oracle's frame-by-frame sums, equal up to fp32 summation order; a second launch reuses the plan."""

@@ -325,3 +325,14 @@ def test_malformed_bvh_is_rejected(pt, scenes):
     with pytest.raises(pt.PtError):
         r.render(1)
     r.close()
+
+
+def test_reference_dispatch_smaller_than_one_group(pt, scenes):
+    """PT_FLAG_REFERENCE_DISPATCH renders floor(w/16) x floor(h/16) groups of 16x16 pixels (renderer.rs:565-569): an
+    image lower than 16 pixels gets none, in single dispatches, short fused launches and planned ones alike."""
+    r = pt.Renderer(scenes.cornell(), 58, 10, settings=pt.Settings(2, 3, 1e-4, 1000.0), flags=pt.PT_FLAG_REFERENCE_DISPATCH)
+    r.render(5)
+    r.render_frames(6, 3, 13)
+    r.render_frames(100, 1, 40)
+    assert (r.read_sum() == 0).all() and r.stats()["rays"] == 0 and r.stats()["frames"] == 54
+    r.close()
