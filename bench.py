@@ -186,8 +186,8 @@ def main():
                        "parallelism": f"sample-split x{world}, one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "pool_kernel for this workload (library default at 1 spp per frame for meshes >= 8192 triangles in launches >= 48 "
-                                   "frames and meshes >= 512 triangles in launches >= 192 frames; trace_kernel otherwise), + accumulate_kernel; plan_kernel and the per-tile cost "
+                         "kernel": "pool_kernel for this workload (library default for meshes >= 8192 triangles in launches >= 48 samples per pixel "
+                                   "and smaller meshes in launches >= 192; trace_kernel otherwise), + accumulate_kernel; plan_kernel and the per-tile cost "
                                    "measurement run in the first two launches of a configuration (warm-up), identical launches then reuse the "
                                    "work-item table; a 4-frame probe launch in the very first step",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
