@@ -69,3 +69,25 @@ def test_1080p_frames_match_oracle(pt, po, scenes, name):
     assert r.stats()["rays"] == rays and (got[..., 3] == n).all()
     np.testing.assert_allclose(got, want, rtol=n * 2.0 ** -23, atol=1e-6)
     r.close()
+
+
+def test_1080p_several_samples_per_frame_match_oracle(pt, po, scenes):
+    """The mesh scene at 3 samples per pixel and frame: one dispatch bit-exact, then a 16-frame launch (48 samples per
+    pixel: planned into work items by samples) with exact ray counts and sums equal up to summation order."""
+    scene, w, h, st, _, sky = _config(pt, scenes, "bunny_1080p_d8_spp256", 64)
+    st = pt.Settings(3, st.depth, st.t_min, st.t_max)
+    osc = po.from_scene(scene, w, h, st, sky)
+    r = pt.Renderer(scene, w, h, settings=st)
+    r.set_sky_cube(sky)
+    r.render(9)
+    want, _, _, ost = osc.render(9)
+    _exact(r.read_sum(), want, "one 1080p frame of 3 samples")
+    rays, n = ost["rays"], 16
+    r.render_frames(50, 2, n)
+    for f in range(n):
+        want, _, _, ost = osc.render(50 + 2 * f, want)
+        rays += ost["rays"]
+    got = r.read_sum()
+    assert r.stats()["rays"] == rays and (got[..., 3] == n + 1).all()
+    np.testing.assert_allclose(got, want, rtol=(n + 1) * 2.0 ** -23, atol=1e-6)
+    r.close()
