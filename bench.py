@@ -188,8 +188,8 @@ def main():
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "pool_kernel for this workload (library default for meshes >= 8192 triangles in launches >= 48 samples per pixel "
                                    "and smaller meshes in launches >= 192; trace_kernel otherwise), + accumulate_kernel; plan_kernel and the per-tile cost "
-                                   "measurement run in the first two launches of a configuration (warm-up), identical launches then reuse the "
-                                   "work-item table; a 4-frame probe launch in the very first step",
+                                   "measurement run in the first two launches of a configuration (warm-up) and then in two of every eight; the other "
+                                   "identical launches reuse the work-item table; a 4-frame probe launch in the very first step",
                          "kernel_ms": k_ms, "flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": abytes,
                          "algorithmic_GBps": abytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,

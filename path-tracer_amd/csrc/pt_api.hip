@@ -716,9 +716,20 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
             key.max_chunk = bs.max_chunk;
             key.min_chunk = bs.min_chunk;
             key.use_pool = use_pool;
+            // Identical launches one after the other (same scene, image, length; the time differs).  The per-tile
+            // kernel plans each of them afresh from the launch before: its items are bound to waves up front, and a
+            // plan gone stale costs it dearly (cost moves with the time: on coarse meshes some spans of 192 frames are
+            // twice as expensive in some tiles, and a stale plan then took 26-52 ms instead of 15).  The pooled
+            // kernel hands items out as slots fall free and loses less to a stale plan (20 ms instead of 15) while
+            // skipping the planning and the cost measurement gains it 3-15 %: it plans launches 1 and 2, runs that
+            // plan for six launches, measures during the seventh, plans the eighth anew, and so on.
             if (key == ctx->plan_key) {
-                bs.reuse_plan = ctx->plans_for_key >= 2 && ctx->cost_valid && !getenv("PTRT_ALWAYS_PLAN");
-                if (!bs.reuse_plan) ctx->plans_for_key++;
+                const uint32_t launch = ++ctx->plans_for_key;  // 2, 3, ... with this key
+                if (use_pool && launch >= 3u && ctx->cost_valid && !getenv("PTRT_ALWAYS_PLAN")) {
+                    const uint32_t phase = (launch - 3u) % PT_PLAN_REUSE_PERIOD;
+                    bs.reuse_plan = phase + 1u < PT_PLAN_REUSE_PERIOD;
+                    bs.measure_cost = phase + 2u == PT_PLAN_REUSE_PERIOD;
+                }
             } else {
                 ctx->plan_key = key;
                 ctx->plans_for_key = 1;

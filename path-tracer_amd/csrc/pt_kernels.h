@@ -31,6 +31,7 @@
 #define PT_POOL_MULTI_MIN_FRAMES 16u
 #define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
+#define PT_PLAN_REUSE_PERIOD 8u  // pooled kernel, identical launches: of 8, six run the old plan, one also measures, one plans anew
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
@@ -108,6 +109,7 @@ struct PtSchedule {
     uint32_t n_cus;               // compute units of the device
     uint32_t pool_groups;         // workgroups to launch; 0 = as many as are resident at once
     bool reuse_plan;              // the item table, tile table and buffers still hold the plan of an identical launch: run it again
+    bool measure_cost;            // ... and measure the per-tile cost meanwhile, for a new plan next time
 };
 
 // stack_depth: deepest leaf of the BVH (bound on traversal stack entries).

@@ -2005,6 +2005,9 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
                            sch.min_chunk, sch.items, cap, sch.tile_items, sch.sorted);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
+    } else if (sch.measure_cost) {
+        if ((e = hipMemsetAsync(sch.cost, 0, (size_t)p.n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        p.cost = sch.cost;
     }
     p.items = sch.items;
     p.partial = sch.partial;

@@ -129,10 +129,11 @@ def test_automatic_choice_by_mesh_size(pt, scenes):
 
 @pytest.mark.parametrize("flag", ["PT_FLAG_POOL_KERNEL", "PT_FLAG_TILE_KERNEL"])
 def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
-    """From the third identical launch on the work-item table of the previous launch is run again (no planning, no
-    cost measurement); setting anything on the context ends that.  Every launch must still trace every sample: ray
-    counts and frame counts exact, sums equal to the oracle's up to summation order, and two contexts fed the same
-    call sequence agree bit for bit."""
+    """Pooled kernel: from the third identical launch on the work-item table of the previous launch is run again
+    (no planning, no cost measurement), the ninth measures the cost again and the tenth plans anew; setting anything
+    on the context ends that.  The per-tile kernel plans every launch.  Every launch must still trace every sample:
+    ray counts and frame counts exact, sums equal to the oracle's up to summation order, and two contexts fed the
+    same call sequence agree bit for bit."""
     scene = scenes.bunny(n=12)
     sky = scenes.sky_cube_direct(16)
     st = pt.Settings(1, 6, 1e-4, 1000.0)
@@ -142,7 +143,7 @@ def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
     rays = 0
 
     def run(r):
-        for k in range(5):              # launches 3..5 reuse the plan of launch 2
+        for k in range(12):             # pooled: launches 3..8 reuse the plan of launch 2, 9 measures, 10 plans, 11.. reuse
             r.render_frames(1 + k * n, 1, n)
         moved = pt.Scene(scene.spheres, scene.triangles, pt.Camera.from_yaw_pitch((0.8, 1.1, 4.2), -92.0, -3.0))
         r.update_scene(moved)           # new camera: the old plan must not be run again blindly (it would still be correct)
@@ -161,7 +162,7 @@ def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
     r1.close()
     r2.close()
     assert np.array_equal(got.view(np.uint32), got2.view(np.uint32)) and stats == stats2
-    for k in range(5):
+    for k in range(12):
         for f in range(n):
             want, _, _, ost = osc.render(1 + k * n + f, want)
             rays += ost["rays"]
@@ -171,5 +172,5 @@ def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
         for f in range(n):
             want, _, _, ost = osc2.render(1000 + k * n + f, want)
             rays += ost["rays"]
-    assert stats["rays"] == rays and stats["frames"] == 8 * n and (got[..., 3] == 8 * n).all()
-    np.testing.assert_allclose(got, want, rtol=8 * n * 2.0 ** -23, atol=1e-6)
+    assert stats["rays"] == rays and stats["frames"] == 15 * n and (got[..., 3] == 15 * n).all()
+    np.testing.assert_allclose(got, want, rtol=15 * n * 2.0 ** -23, atol=1e-6)
