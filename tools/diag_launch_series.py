@@ -21,7 +21,7 @@ for k in range(10):
     if os.environ.get("STATS"):
         r.stats()
     t0 = time.perf_counter()
-    r.render_frames(1 + (0 if os.environ.get('SAME_TIME') else k) * frames, 1, frames); r.sync()
+    r.render_frames(int(os.environ.get('BASE', '1')) + (0 if os.environ.get('SAME_TIME') else k) * frames, 1, frames); r.sync()
     out.append((time.perf_counter() - t0) * 1e3)
 print(f"{len(scene.triangles)} triangles, {frames} frames:", " ".join(f"{v:.2f}" for v in out), "ms")
 r.close()
