@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 
 namespace {
@@ -103,6 +104,23 @@ struct Walk {
 };
 
 // Returns true if there is a BVH to walk (w.node/w.sp valid), false if the hit is already final.
+// The root's child pair, re-read from the kernel-argument segment at the point of use (the scene block is the first
+// member of every kernel's parameter block): fourteen scalar registers that are live for one box test instead of
+// for the whole shading pass.
+typedef const __attribute__((address_space(4))) uint32_t *PtKernargWords;
+static_assert(offsetof(PtTraceParams, sc) == 0 && offsetof(PtRayQuery, sc) == 0, "the scene block leads the kernel arguments");
+__device__ __forceinline__ void pt_fresh_root_pair(float4 &q0, float4 &q1, float4 &q2, uint32_t &k1, uint32_t &k2)
+{
+    PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kw));
+    constexpr uint32_t o = offsetof(PtDeviceScene, root_pair) / 4;
+    q0 = make_float4(__uint_as_float(kw[o + 0]), __uint_as_float(kw[o + 1]), __uint_as_float(kw[o + 2]), __uint_as_float(kw[o + 3]));
+    q1 = make_float4(__uint_as_float(kw[o + 4]), __uint_as_float(kw[o + 5]), __uint_as_float(kw[o + 6]), __uint_as_float(kw[o + 7]));
+    q2 = make_float4(__uint_as_float(kw[o + 8]), __uint_as_float(kw[o + 9]), __uint_as_float(kw[o + 10]), __uint_as_float(kw[o + 11]));
+    k1 = kw[o + 12];
+    k2 = kw[o + 13];
+}
+
 template <bool STATS, typename StackT>
 __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
 {
@@ -158,8 +176,10 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     // rays of an outdoor scene end their walk right here.
     if (STATS) cn.interior++;
     float d1, d2;
-    hit_aabb_pair(o, w.inv, sc.root_pair[0], sc.root_pair[1], sc.root_pair[2], d1, d2);
-    uint32_t k1 = __float_as_uint(sc.root_pair[3].x), k2 = __float_as_uint(sc.root_pair[3].y);
+    float4 r0, r1, r2;
+    uint32_t k1, k2;
+    pt_fresh_root_pair(r0, r1, r2, k1, k2);
+    hit_aabb_pair(o, w.inv, r0, r1, r2, d1, d2);
     if (d1 > d2) {
         const float td = d1; d1 = d2; d2 = td;
         const uint32_t tk = k1; k1 = k2; k2 = tk;
@@ -537,8 +557,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // vector instructions in the walk loop.  The shading pass and the job hand-out therefore re-read the
 // block from the kernel-argument segment (scalar loads, live only while they run); the asm statement
 // keeps the compiler from hoisting those loads back out of the loop.
-typedef const __attribute__((address_space(4))) uint32_t *PtKernargWords;
 static_assert(sizeof(PtTraceParams) % 4 == 0, "parameter block is read word by word");
+// A pointer rebuilt from plain words is a generic-address pointer, dereferenced through the slower flat path.  Every
+// pointer of the block points to global memory: saying so (a cast to the global address space and back, which the
+// compiler's address-space inference follows through the inlined callees) turns those accesses into global ones,
+// so that no pointer has to be kept in scalar registers across the persistent loop just to keep its address space.
+template <typename T>
+__device__ __forceinline__ void pt_mark_global(T *&p)
+{
+    typedef __attribute__((address_space(1))) T *G;
+    p = (T *)(G)(uintptr_t)p;
+}
 __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 {
     PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();  // the block is the kernel's only argument
@@ -546,22 +575,16 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
     uint32_t *lw = reinterpret_cast<uint32_t *>(&L);
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
+    pt_mark_global(L.sc.spheres); pt_mark_global(L.sc.nodes); pt_mark_global(L.sc.node_meta);
+    pt_mark_global(L.sc.tri_pos); pt_mark_global(L.sc.tri_nrm); pt_mark_global(L.sc.sky);
+    pt_mark_global(L.items); pt_mark_global(L.partial); pt_mark_global(L.cost); pt_mark_global(L.accum);
+    pt_mark_global(L.aov_prim); pt_mark_global(L.aov_t); pt_mark_global(L.counters); pt_mark_global(L.gstack);
+    pt_mark_global(L.next_item);
 }
-// The pointers used in inner loops are taken from the kernel argument itself: the compiler knows that those
-// point to global memory, while a pointer rebuilt from plain words is dereferenced through the slower
-// generic-address path.  The rarely used ones (primary-hit output) stay rebuilt, so that their kernel-argument
-// values need not live in scalar registers across the persistent loop.
-#define PT_FRESH_PARAMS(L)                                                                                       \
-    PtTraceParams L;                                                                                             \
-    pt_fresh_params(L);                                                                                          \
-    L.sc.spheres = P.sc.spheres; L.sc.nodes = P.sc.nodes; L.sc.node_meta = P.sc.node_meta;                      \
-    L.sc.tri_pos = P.sc.tri_pos; L.sc.tri_nrm = P.sc.tri_nrm; L.sc.sky = P.sc.sky;                              \
-    L.items = P.items; L.partial = P.partial; L.cost = P.cost; L.accum = P.accum;                               \
-    L.next_item = P.next_item
-// (the per-tile kernel keeps few scalars live and is faster with all its pointers taken from the argument)
-#define PT_FRESH_PARAMS_ALL(L) \
-    PT_FRESH_PARAMS(L);        \
-    L.aov_prim = P.aov_prim; L.aov_t = P.aov_t
+#define PT_FRESH_PARAMS(L) \
+    PtTraceParams L;       \
+    pt_fresh_params(L)
+#define PT_FRESH_PARAMS_ALL(L) PT_FRESH_PARAMS(L)
 
 // ---- the megakernel ---------------------------------------------------------------------
 // GIZMO: some sphere has material 3 (only then is the path's first direction kept);
@@ -885,6 +908,7 @@ struct PPShared {
     uint32_t job_word;           // generation << 8 | pixels handed out (64 = all)
     uint32_t job_lock;           // held by the lane that opens the next item
     uint32_t no_more;            // the launch's item counter is exhausted
+    uint32_t group;              // the workgroup's index, parked here for the end of the kernel
     pp_u32x4 item;               // x0 | y0 << 16, first frame, end frame, item index (read after an acquire fence)
 };
 
@@ -1010,6 +1034,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         sh.job_word = 64u;
         sh.job_lock = 0;
         sh.no_more = 0;
+        sh.group = blockIdx.x;
     }
     __syncthreads();
 
@@ -1256,9 +1281,13 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
             dg_s = clock64();
 #endif
-            PT_FRESH_PARAMS(L);
-            const PtDeviceScene &sc = L.sc;
-            float4 *const sums = DIRECT ? L.accum : L.partial;
+            // The parameter block is re-read from the kernel-argument segment stage by stage (each PT_FRESH_PARAMS loads
+            // only the words its stage uses, right there), so that no stage's scalars are live during another one.
+            uint32_t miss_iters;
+            {
+                PT_FRESH_PARAMS(L0);
+                miss_iters = L0.pool_miss_iters;
+            }
             bool to_pending = false, to_ready = false, to_hit = false, finished = false;
             uint32_t p = 0xFFFFFFFFu;
             // One body, compiled twice: in a pass over hits every lane has a ray that hit something, in a
@@ -1275,13 +1304,19 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 if (p == 0xFFFFFFFFu) return;
                 const uint32_t xy = sh.st[F_XY][p], x = xy & 0xFFFFu, y = xy >> 16;
                 const uint32_t frame_end = sh.st[F_FEND][p], pidx = sh.st[F_PIDX][p];
-                float4 acc = sums[pidx];
+                float4 acc;
+                uint32_t depth;
+                {
+                    PT_FRESH_PARAMS(LA);
+                    acc = (DIRECT ? LA.accum : LA.partial)[pidx];
+                    depth = LA.depth;
+                }
                 const uint32_t fs = sh.st[F_FS][p];
                 const bool had_ray = HITS || (fs & 1u) != 0;
                 bool want_aov = (fs & 2u) != 0;
                 uint32_t sample = fs >> 2;
                 uint32_t frame = sh.st[F_FRAME][p];
-                uint32_t bounce = 0, limit = L.depth;
+                uint32_t bounce = 0, limit = depth;
                 v3 color = V3(1.0f, 1.0f, 1.0f), initial_d = V3(0.0f, 0.0f, 0.0f);
                 float seed = 0.0f;
                 Ray cur;
@@ -1290,6 +1325,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 v3 path_color = V3(0.0f, 0.0f, 0.0f);    // its colour (a miss: still to be multiplied by the sky texel)
                 v3 sky = V3(1.0f, 1.0f, 1.0f);
                 if (had_ray) {
+                    PT_FRESH_PARAMS(L);
+                    const PtDeviceScene &sc = L.sc;
                     cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
                     color = V3(__uint_as_float(sh.st[F_COLR][p]), __uint_as_float(sh.st[F_COLG][p]), __uint_as_float(sh.st[F_COLB][p]));
                     if constexpr (!HITS) {
@@ -1339,7 +1376,12 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 bool frame_ends = false;
                 if (retire) {
                     if constexpr (!SPP1) sample++;
-                    if (SPP1 || sample == L.spp) {
+                    bool last = true;
+                    if constexpr (!SPP1) {
+                        PT_FRESH_PARAMS(L);
+                        last = sample == L.spp;
+                    }
+                    if (last) {
                         frame_ends = true;
                         sample = 0;
                         frame++;
@@ -1348,10 +1390,12 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 }
                 const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
                 if (finished) {
+                    PT_FRESH_PARAMS(L);
                     if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
                 } else {
                     if (!had_ray || retire) {
                         // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
+                        PT_FRESH_PARAMS(L);
                         uint32_t sx, sy, sz, sw;
                         const uint32_t time = L.time0 + frame * L.stride;  // compute.wgsl:85
                         sx = x; sy = y; sz = x + time; sw = y + time;
@@ -1379,7 +1423,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     // spheres + root visit; a surviving ray goes to PENDING with its first node(s)
                     Walk nw;
                     uint32_t k2 = 0xFFFFFFFFu;
-                    const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
+                    bool need_walk;
+                    {
+                        PT_FRESH_PARAMS(L);
+                        need_walk = walk_begin_pool<STATS>(L.sc, cur, nw, k2, cn);
+                    }
 #ifdef PT_DIAG
                     if (!HITS) { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
 #endif
@@ -1413,9 +1461,10 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         path_color = V3(__uint_as_float(sh.st[FL::FSUM][p]), __uint_as_float(sh.st[FL::FSUM + 1][p]), __uint_as_float(sh.st[FL::FSUM + 2][p])) + path_color;
                     if (frame_ends) {
                         // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                        PT_FRESH_PARAMS(L);
                         const v3 mean = path_color * L.inv_spp;
                         acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
-                        sums[pidx] = acc;
+                        (DIRECT ? L.accum : L.partial)[pidx] = acc;
                         path_color = V3(0.0f, 0.0f, 0.0f);
                     }
                     if constexpr (!SPP1) {
@@ -1444,7 +1493,10 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     y = xy >> 16;
                     frame_end = sh.st[F_FEND][p];
                     pidx = sh.st[F_PIDX][p];
-                    acc = sums[pidx];
+                    {
+                        PT_FRESH_PARAMS(LA);
+                        acc = (DIRECT ? LA.accum : LA.partial)[pidx];
+                    }
                     const uint32_t fs = sh.st[F_FS][p];
                     have_ray = (fs & 1u) != 0;
                     want_aov = (fs & 2u) != 0;
@@ -1461,6 +1513,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     }
                 }
                 for (uint32_t round = 0;; round++) {
+                    PT_FRESH_PARAMS(L);
+                    const PtDeviceScene &sc = L.sc;
                     if (mine) {
                         // the ray in hand missed everything: compute.wgsl:140-143
                         v3 sky = V3(1.0f, 1.0f, 1.0f), path_color = color;
@@ -1506,7 +1560,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             cn.rays++;
                             Walk nw;
                             uint32_t k2 = 0xFFFFFFFFu;
-                            const bool need_walk = walk_begin_pool<STATS>(sc, cur, nw, k2, cn);
+                            bool need_walk;
+                            {
+                                PT_FRESH_PARAMS(LW);
+                                need_walk = walk_begin_pool<STATS>(LW.sc, cur, nw, k2, cn);
+                            }
                             if (need_walk || nw.rec.hit) {
                                 // this ray goes on elsewhere: the slot's whole state to LDS
                                 sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
@@ -1554,7 +1612,10 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     if (n_mine < L.pool_miss_lanes || round + 1u >= L.pool_miss_iters) break;
                 }
                 if (p != 0xFFFFFFFFu) {
-                    if (dirty) sums[pidx] = acc;
+                    if (dirty) {
+                        PT_FRESH_PARAMS(LA);
+                        (DIRECT ? LA.accum : LA.partial)[pidx] = acc;
+                    }
                     if constexpr (!SPP1) {
                         // (a lane that left with a hit or a walk stored its RNG state above; the sample sum is common)
                         sh.st[FL::FSUM][p] = __float_as_uint(fsum.x); sh.st[FL::FSUM + 1][p] = __float_as_uint(fsum.y); sh.st[FL::FSUM + 2][p] = __float_as_uint(fsum.z);
@@ -1572,7 +1633,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 }
             };
             if (pass_hits) shading_pass(std::true_type{});
-            else if (L.pool_miss_iters > 1u) miss_pass();
+            else if (miss_iters > 1u) miss_pass();
             else shading_pass(std::false_type{});
 #ifdef PT_DIAG
             if (!pass_hits) { const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
@@ -1637,12 +1698,13 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 
     PtTraceParams LE;  // (re-read: the counters' address is not kept in registers through the loop)
     pt_fresh_params(LE);
+    const uint32_t stripe = lds_load_uniform(&sh.group) % PT_COUNTER_STRIPES;
     uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
     const int ncount = STATS ? PT_NUM_COUNTERS : 1;
     for (int k = 0; k < ncount; k++) {
         if (k == 1) continue;
         const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&LE.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH + k], (unsigned long long)s);
+        if (lane == 0 && s) atomicAdd(&LE.counters[stripe * PT_COUNTER_PITCH + k], (unsigned long long)s);
     }
 }
 
