@@ -62,6 +62,16 @@ class Stats(C.Structure):
 
 
 _lib = None
+# PTRT_KERNEL=pool|tile in the environment (read once, here; the library itself does not look at it) forces a
+# megakernel for every Renderer of the process: used by the scripts under tools/.
+_forced_flags = {"p": PT_FLAG_POOL_KERNEL, "t": PT_FLAG_TILE_KERNEL}.get(os.environ.get("PTRT_KERNEL", " ")[:1], 0)
+
+
+def force_kernel(kind: Optional[str]):
+    """Test aid: every Renderer made from now on gets PT_FLAG_POOL_KERNEL ("pool") or PT_FLAG_TILE_KERNEL ("tile")
+    added to its flags; None restores the library's own choice."""
+    global _forced_flags
+    _forced_flags = {None: 0, "pool": PT_FLAG_POOL_KERNEL, "tile": PT_FLAG_TILE_KERNEL}[kind]
 
 # every symbol include/ptrt.h declares: (name, restype, argtypes)
 _VP, _U32, _I = C.c_void_p, C.c_uint32, C.c_int
@@ -275,7 +285,7 @@ class Renderer:
         self.settings = settings or Settings()
         if stream:
             self._ck(self._l.pt_set_stream(self._ctx, C.c_void_p(stream)))
-        if flags:
+        if flags or _forced_flags:
             self.set_flags(flags)
         self.set_mesh(scene.triangles, scene.nodes, scene.triangle_indices)
         self.update_scene(scene)
@@ -296,6 +306,8 @@ class Renderer:
             pass
 
     def set_flags(self, flags: int):
+        if not flags & (PT_FLAG_POOL_KERNEL | PT_FLAG_TILE_KERNEL):
+            flags |= _forced_flags
         self._ck(self._l.pt_set_flags(self._ctx, flags))
 
     def set_mesh(self, triangles: np.ndarray, nodes: np.ndarray, tri_idx: np.ndarray):

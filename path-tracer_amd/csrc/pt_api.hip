@@ -199,13 +199,19 @@ int ensure_gstack(pt_ctx *ctx, size_t bytes)
     return PT_OK;
 }
 
-// Tuning aid: an environment override of a launch heuristic, read at every launch (tools/sweep_*.sh);
-// unset in normal use.
+// Launch heuristics are constants.  Only a -DPT_TUNING build (make tuning; used by tools/sweep_*.sh) lets PTRT_*
+// environment variables override them, read at every launch.
+#ifdef PT_TUNING
 inline uint32_t env_u32(const char *name, uint32_t fallback)
 {
     const char *e = getenv(name);
     return e ? (uint32_t)strtoul(e, nullptr, 10) : fallback;
 }
+inline const char *env_str(const char *name) { return getenv(name); }
+#else
+inline uint32_t env_u32(const char *, uint32_t fallback) { return fallback; }
+inline const char *env_str(const char *) { return nullptr; }
+#endif
 
 inline float u2f(uint32_t u)
 {
@@ -582,7 +588,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
                     launch_frames >= PT_POOL_MULTI_MIN_FRAMES);
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
-    if (const char *env = getenv("PTRT_KERNEL")) {  // "pool" / "tile": tuning and test aid, overrides the flags
+    if (const char *env = env_str("PTRT_KERNEL")) {  // "pool" / "tile": tuning builds only, overrides the flags
         if (env[0] == 'p') use_pool = true;
         else if (env[0] == 't') use_pool = false;
     }
@@ -600,7 +606,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     // favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s).  Pooled kernel: half a
     // wave's worth (48 for a wave that is busy walking); waiting for full passes was better only before misses
     // stayed in registers (bench scene 32.5 vs 31.5 Grays/s, 10 M-triangle field 4.76 vs 4.46).
-    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? 32 : (ctx->n_tri_slots >= PT_TILE_EARLY_SHADE_TRIANGLES ? 24 : 48));
+    p.refill_lanes = env_u32("PTRT_REFILL_LANES", use_pool ? PT_POOL_REFILL_LANES : (ctx->n_tri_slots >= PT_TILE_EARLY_SHADE_TRIANGLES ? 24 : 48));
 
     PtSchedule sch{};
     sch.cost = ctx->tile_cost;
@@ -625,20 +631,20 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     sch.min_planned_frames = env_u32("PTRT_MIN_PLANNED", 2);
     const uint32_t regroup_frames = 16;
     sch.probe_frames = 4;
-    if (getenv("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
+    if (env_str("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
     sch.use_pool = use_pool;
     sch.next_item = ctx->next_item;
     sch.pool_gstack = ctx->pool_gstack;
     sch.n_cus = ctx->n_cus;
     sch.pool_groups = env_u32("PTRT_POOL_GROUPS", 0);
-    p.pool_start = env_u32("PTRT_POOL_START", 32);
-    p.pool_topup = env_u32("PTRT_POOL_TOPUP", 16);
-    p.pool_dense = env_u32("PTRT_POOL_DENSE", 16);
-    p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", 48);
-    p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", 32);
-    p.pool_miss_lanes = env_u32("PTRT_POOL_MISS_LANES", 48);
-    p.pool_steps = env_u32("PTRT_POOL_STEPS", 8);
-    p.max_idle = 1u << 22;
+    p.pool_start = env_u32("PTRT_POOL_START", PT_POOL_START);  // (the kernel reads these in tuning builds only)
+    p.pool_topup = env_u32("PTRT_POOL_TOPUP", PT_POOL_TOPUP);
+    p.pool_dense = env_u32("PTRT_POOL_DENSE", PT_POOL_DENSE);
+    p.pool_shade_dense = env_u32("PTRT_POOL_SHADE_DENSE", PT_POOL_SHADE_DENSE);
+    p.pool_miss_iters = env_u32("PTRT_POOL_MISS_ITERS", PT_POOL_MISS_ITERS);
+    p.pool_miss_lanes = env_u32("PTRT_POOL_MISS_LANES", PT_POOL_MISS_LANES);
+    p.pool_steps = env_u32("PTRT_POOL_STEPS", PT_POOL_STEPS);
+    p.max_idle = PT_POOL_MAX_IDLE;
 
     // the per-lane ray counter is 32 bits: bound the frames of one launch
     const uint64_t per_frame = (uint64_t)ctx->settings.samples_per_pixel * ((uint64_t)ctx->settings.depth + PT_MAX_SPHERES);
@@ -688,7 +694,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         p.n_frames = batch;
         uint32_t blocks = ctx->n_tiles;
         PtSchedule bs = sch;  // this batch's schedule
-        if (batch < regroup_frames && !getenv("PTRT_MAX_CHUNK")) {
+        if (batch < regroup_frames && !env_str("PTRT_MAX_CHUNK")) {
             bs.max_chunk = 1;
             bs.min_chunk = 1;
             // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: not beyond 2 GiB
@@ -725,7 +731,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
             // plan for six launches, measures during the seventh, plans the eighth anew, and so on.
             if (key == ctx->plan_key) {
                 const uint32_t launch = ++ctx->plans_for_key;  // 2, 3, ... with this key
-                if (use_pool && launch >= 3u && ctx->cost_valid && !getenv("PTRT_ALWAYS_PLAN")) {
+                if (use_pool && launch >= 3u && ctx->cost_valid && !env_str("PTRT_ALWAYS_PLAN")) {
                     const uint32_t phase = (launch - 3u) % PT_PLAN_REUSE_PERIOD;
                     bs.reuse_plan = phase + 1u < PT_PLAN_REUSE_PERIOD;
                     bs.measure_cost = phase + 2u == PT_PLAN_REUSE_PERIOD;
@@ -767,7 +773,7 @@ int pt_reset(pt_ctx *ctx)
     ctx->frames = 0;
     ctx->paths = 0;
     if (ctx->window_size) ctx->ready_samples = 1;  // reset_ready_samples, renderer.rs:635-637 (the textures keep their contents)
-    PT_HIP(ctx, hipMemsetAsync(ctx->next_item + 1, 0, sizeof(uint32_t), ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->next_item + 1, 0, 2 * sizeof(uint32_t), ctx->stream));
     return PT_OK;
 }
 
@@ -776,9 +782,13 @@ namespace {
 // waits exist so that a defect cannot hang the GPU)?  The image is then incomplete.
 int check_gave_up(pt_ctx *ctx)
 {
-    uint32_t gave_up = 0;
-    PT_HIP(ctx, hipMemcpy(&gave_up, ctx->next_item + 1, sizeof gave_up, hipMemcpyDeviceToHost));
-    if (gave_up) return fail(ctx, PT_ERR_INTERNAL, "pooled kernel: %u waves gave up waiting; the accumulated image is incomplete (pt_reset and use PT_FLAG_TILE_KERNEL)", gave_up);
+    uint32_t w[2] = {0, 0};  // waves that gave up, self-check bits (PT_KERR_* in pt_kernels.hip)
+    PT_HIP(ctx, hipMemcpy(w, ctx->next_item + 1, sizeof w, hipMemcpyDeviceToHost));
+    if (w[0] || w[1])
+        return fail(ctx, PT_ERR_INTERNAL,
+                    "pooled kernel: %u waves gave up waiting%s%s%s%s; the accumulated image is incomplete (pt_reset and use PT_FLAG_TILE_KERNEL)", w[0],
+                    (w[1] & 1u) ? "; a ring entry was overwritten" : "", (w[1] & 2u) ? "; a claimed ring entry was never filled" : "",
+                    (w[1] & 4u) ? "; a ring held a slot id beyond the pool" : "", (w[1] & 8u) ? "; a slot's sums index was out of range" : "");
     return PT_OK;
 }
 }  // namespace

@@ -32,13 +32,24 @@
 #define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
 #define PT_PLAN_REUSE_PERIOD 8u  // pooled kernel, identical launches: of 8, six run the old plan, one also measures, one plans anew
+// pooled kernel: scheduling thresholds (see PtTraceParams for what each one means)
+#define PT_POOL_START 32u
+#define PT_POOL_TOPUP 16u
+#define PT_POOL_DENSE 16u
+#define PT_POOL_SHADE_DENSE 48u
+#define PT_POOL_REFILL_LANES 32u
+#define PT_POOL_STEPS 8u
+#define PT_POOL_MISS_ITERS 32u
+#define PT_POOL_MISS_LANES 48u
+#define PT_POOL_MAX_IDLE (1u << 22)
 #define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
 
 struct PtDeviceScene {
     // spheres: 3 float4 each {center, radius} {albedo, material} {1/radius, 0, 0, 0}
     const float4 *spheres;
     uint32_t n_spheres;
-    // BVH: 2 float4 per node {min, token} {max, count}, indexed by the reference's node index
+    // BVH: 4 float4 per sibling pair (l, l+1), interleaved {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
+    // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}; nodes + 2*l is the pair of the children l, l+1
     const float4 *nodes;
     const uint2 *node_meta;  // (first, count) per node, read for big leaves only
     uint32_t n_nodes;
@@ -67,7 +78,7 @@ struct PtTraceParams {
     uint32_t tiles_x, tiles_y, n_tiles;  // filled in by pt_launch_trace
     const uint4 *items;      // filled in by pt_launch_trace: {tile, first frame, frame count, 0} per work item
     float4 *partial;         // filled in by pt_launch_trace: 64 partial sums per work item
-    uint32_t *cost;          // filled in by pt_launch_trace: per-tile wave time of this launch (10 ns ticks)
+    uint32_t *cost;          // filled in by pt_launch_trace: per-tile work of this launch (node visits + 8 per shading pass)
     float4 *accum;
     uint32_t *aov_prim;  // may be null
     float *aov_t;

@@ -584,7 +584,6 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 #define PT_FRESH_PARAMS(L) \
     PtTraceParams L;       \
     pt_fresh_params(L)
-#define PT_FRESH_PARAMS_ALL(L) PT_FRESH_PARAMS(L)
 
 // ---- the megakernel ---------------------------------------------------------------------
 // GIZMO: some sphere has material 3 (only then is the path's first direction kept);
@@ -733,11 +732,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #endif
             // (the shading block re-reads the parameter block, so that the walk loop does not have to keep
             // all of it in scalar registers)
-            PT_FRESH_PARAMS_ALL(L);
+            // (stage by stage, so that no stage's scalars are live during another one)
             if (mode == M_SHADE) {
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 if (!need_new) {
+                    PT_FRESH_PARAMS(L);
                     uint32_t prim;
                     path_done = shade_ray<STATS, GIZMO>(L.sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
                     if (want_aov) {
@@ -746,8 +746,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
                         want_aov = false;
                     }
                 }
-                advance(L, path_done, result);
+                {
+                    PT_FRESH_PARAMS(L);
+                    advance(L, path_done, result);
+                }
                 if (active) {
+                    PT_FRESH_PARAMS(L);
                     cn.rays++;
                     mode = walk_begin<STATS>(L.sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
@@ -857,6 +861,14 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_k
 #define PT_PP_STACK 8    // traversal stack entries per walk slot kept in LDS; deeper ones spill
 #endif
 #define PT_PP_MAX_SPIN (1u << 20)
+// Scheduling thresholds of the pooled kernel.  They are compile-time constants (the values measured best on the
+// benchmark scenes); only a -DPT_TUNING build (make tuning) reads them from the parameter block, where the PTRT_*
+// environment variables of the sweep scripts put them.
+#ifdef PT_TUNING
+#define PT_TUNE(field, value) (field)
+#else
+#define PT_TUNE(field, value) (value)
+#endif
 #ifndef PT_PP_WAVES_PER_EU
 #define PT_PP_WAVES_PER_EU 4
 #endif
@@ -939,6 +951,28 @@ struct PPStack {
     }
 };
 
+// Self-checks of the pooled kernel.  None of them is expected to fire; each costs a compare on a path that is taken
+// anyway, and a violated one names itself in the launch's error word (bit per kind, read by the host after a
+// synchronisation) instead of showing up later as a hang or a stray memory access.
+#define PT_KERR_RING_OVERWRITE 1u  // a ring position was still occupied after the bounded wait (entry overwritten)
+#define PT_KERR_RING_EMPTY 2u      // a claimed ring position was never filled (slot id lost)
+#define PT_KERR_SLOT_ID 4u         // a ring handed out a slot id beyond the pool
+#define PT_KERR_SUMS_INDEX 8u      // a slot's index into the sums lies outside the buffer
+__device__ __forceinline__ void pt_mark_error(uint32_t bit)
+{
+    PtTraceParams L;  // (re-read: only the word of the error pointer is loaded)
+    pt_fresh_params(L);
+    atomicOr(L.next_item + 2, bit);
+}
+
+__device__ __forceinline__ void ring_wait_empty(pp_entry *e)
+{
+    for (uint32_t spin = 0; ring_load(e) != 0u; spin++) {
+        if (spin >= PT_PP_MAX_SPIN) { pt_mark_error(PT_KERR_RING_OVERWRITE); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Wave-level push: every lane with `mine` appends `id`.  Called from wave-uniform code.
 __device__ __forceinline__ void ring_push(pp_entry *ring, uint32_t *tail, bool mine, uint32_t id, uint32_t lane, unsigned long long lt_mask)
 {
@@ -951,7 +985,7 @@ __device__ __forceinline__ void ring_push(pp_entry *ring, uint32_t *tail, bool m
     if (mine) {
         pp_entry *e = &ring[(base + (uint32_t)__popcll(m & lt_mask)) & (PT_PP_QCAP - 1u)];
         // an older entry not yet taken out: never seen in practice; bounded so that a bug cannot hang the GPU
-        for (uint32_t spin = 0; ring_load(e) != 0u && spin < PT_PP_MAX_SPIN; spin++) __builtin_amdgcn_s_sleep(1);
+        ring_wait_empty(e);
         ring_store(e, id + 1u);
     }
 }
@@ -975,14 +1009,14 @@ __device__ __forceinline__ void ring_push3(pp_entry *r0, uint32_t *t0, bool m0, 
         pp_entry *ring = m0 ? r0 : m1 ? r1 : r2;
         const uint32_t pos = m0 ? base0 + (uint32_t)__popcll(b0 & lt_mask) : m1 ? base1 + (uint32_t)__popcll(b1 & lt_mask) : base2 + (uint32_t)__popcll(b2 & lt_mask);
         pp_entry *e = &ring[pos & (PT_PP_QCAP - 1u)];
-        for (uint32_t spin = 0; ring_load(e) != 0u && spin < PT_PP_MAX_SPIN; spin++) __builtin_amdgcn_s_sleep(1);
+        ring_wait_empty(e);
         ring_store(e, id + 1u);
     }
 }
 
 // Wave-level pop: the lanes of `want` take up to popcount(want) ids; returns 0xFFFFFFFF for no id.
 __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uint32_t *tail, unsigned long long want, uint32_t lane,
-                                            unsigned long long lt_mask)
+                                            unsigned long long lt_mask, uint32_t max_id)
 {
     uint32_t h = 0, n = 0;
     if (lane == 0) {
@@ -1011,6 +1045,9 @@ __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uin
         if (v != 0u) {
             ring_store(e, 0u);
             id = v - 1u;
+            if (id >= max_id) { pt_mark_error(PT_KERR_SLOT_ID); id = 0xFFFFFFFFu; }
+        } else {
+            pt_mark_error(PT_KERR_RING_EMPTY);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1155,7 +1192,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     // max_idle consecutive trips without anything to do (a lost hand-shake would otherwise hang the
     // GPU; the check after the loop reports it).
     uint32_t idle = 0;
-    while (idle < P.max_idle) {
+    while (idle < PT_TUNE(P.max_idle, PT_POOL_MAX_IDLE)) {
         bool did_work = false;
         const bool relaxed = idle >= 2u;      // nothing to do twice in a row: shade whatever is ready
         const bool desperate = idle >= 32u;   // still nothing: walk whatever is pending
@@ -1189,8 +1226,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         }
         const bool leader = best_other < (int32_t)((64u - n_free) * PT_PP_WAVES + (PT_PP_WAVES - 1u - wv));
         if (n_pend != 0u && n_free != 0u &&
-            (desperate || (leader ? (n_free >= P.pool_topup || n_pend >= n_free || n_free == 64u) : n_pend >= P.pool_start + 64u))) {
-            const uint32_t id = ring_pop(sh.pending, &sh.pend_head, &sh.pend_tail, free_mask, lane, lt_mask);
+            (desperate || (leader ? (n_free >= PT_TUNE(P.pool_topup, PT_POOL_TOPUP) || n_pend >= n_free || n_free == 64u) : n_pend >= PT_TUNE(P.pool_start, PT_POOL_START) + 64u))) {
+            const uint32_t id = ring_pop(sh.pending, &sh.pend_head, &sh.pend_tail, free_mask, lane, lt_mask, FL::PATHS);
             if (id != 0xFFFFFFFFu) {
                 const uint32_t p = id;
                 wpath = p;
@@ -1255,7 +1292,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         fin = true;
                     }
                 }
-                if (__ballot(wbusy) == 0ull || k + 1u >= P.pool_steps) break;
+                if (__ballot(wbusy) == 0ull || k + 1u >= PT_TUNE(P.pool_steps, PT_POOL_STEPS)) break;
             }
             __builtin_amdgcn_s_setprio(0);
             ring_push3(sh.ready, &sh.ready_tail, fin && !w.rec.hit, sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, sh.pending, &sh.pend_tail, false, wpath, lane,
@@ -1277,17 +1314,21 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(wbusy));
         const bool pass_hits = n_hit >= n_miss;
         const uint32_t n_ready = pass_hits ? n_hit : n_miss;
-        if (n_ready != 0u && (relaxed || n_ready >= (n_busy >= P.pool_dense ? P.pool_shade_dense : P.refill_lanes) || (n_busy == 0u && n_pend == 0u))) {
+        if (n_ready != 0u && (relaxed || n_ready >= (n_busy >= PT_TUNE(P.pool_dense, PT_POOL_DENSE) ? PT_TUNE(P.pool_shade_dense, PT_POOL_SHADE_DENSE) : PT_TUNE(P.refill_lanes, PT_POOL_REFILL_LANES)) || (n_busy == 0u && n_pend == 0u))) {
 #ifdef PT_DIAG
             dg_s = clock64();
 #endif
             // The parameter block is re-read from the kernel-argument segment stage by stage (each PT_FRESH_PARAMS loads
             // only the words its stage uses, right there), so that no stage's scalars are live during another one.
+#ifdef PT_TUNING
             uint32_t miss_iters;
             {
                 PT_FRESH_PARAMS(L0);
                 miss_iters = L0.pool_miss_iters;
             }
+#else
+            constexpr uint32_t miss_iters = PT_POOL_MISS_ITERS;
+#endif
             bool to_pending = false, to_ready = false, to_hit = false, finished = false;
             uint32_t p = 0xFFFFFFFFu;
             // One body, compiled twice: in a pass over hits every lane has a ray that hit something, in a
@@ -1296,8 +1337,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             // texel of a miss) are issued first, and the next ray is set up before their values are used.
             auto shading_pass = [&](auto hits_tag) {
                 constexpr bool HITS = decltype(hits_tag)::value;
-                p = HITS ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask)
-                         : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+                p = HITS ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask, FL::PATHS)
+                         : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask, FL::PATHS);
 #ifdef PT_DIAG
                 if (!HITS) { const unsigned long long t = clock64(); dg_sec[0] += t - dg_s; dg_s2 = t; }
 #endif
@@ -1308,6 +1349,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 uint32_t depth;
                 {
                     PT_FRESH_PARAMS(LA);
+                    if (pidx >= (DIRECT ? LA.width * LA.height : LA.n_items * 64u)) {
+                        pt_mark_error(PT_KERR_SUMS_INDEX);  // the slot is dropped: its waves give up and the host reports it
+                        p = 0xFFFFFFFFu;
+                        return;
+                    }
                     acc = (DIRECT ? LA.accum : LA.partial)[pidx];
                     depth = LA.depth;
                 }
@@ -1480,7 +1526,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             // needs a walk (state to LDS, slot to the matching ring) or when their job ends, and the loop ends
             // when too few lanes are left or after pool_miss_iters rounds.
             auto miss_pass = [&]() {
-                p = ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask);
+                p = ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask, FL::PATHS);
                 bool mine = p != 0xFFFFFFFFu;  // this lane still carries its slot through the loop
                 uint32_t x = 0, y = 0, frame_end = 0, pidx = 0, frame = 0, sample = 0, cost = 0;
                 bool have_ray = false, want_aov = false, dirty = false;
@@ -1495,7 +1541,14 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     pidx = sh.st[F_PIDX][p];
                     {
                         PT_FRESH_PARAMS(LA);
-                        acc = (DIRECT ? LA.accum : LA.partial)[pidx];
+                        if (pidx >= (DIRECT ? LA.width * LA.height : LA.n_items * 64u)) {
+                            pt_mark_error(PT_KERR_SUMS_INDEX);  // the slot is dropped: its waves give up and the host reports it
+                            pidx = 0;
+                            mine = false;
+                            p = 0xFFFFFFFFu;
+                        } else {
+                            acc = (DIRECT ? LA.accum : LA.partial)[pidx];
+                        }
                     }
                     const uint32_t fs = sh.st[F_FS][p];
                     have_ray = (fs & 1u) != 0;
@@ -1609,7 +1662,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         }
                     }
                     const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine));
-                    if (n_mine < L.pool_miss_lanes || round + 1u >= L.pool_miss_iters) break;
+                    if (n_mine < PT_TUNE(L.pool_miss_lanes, PT_POOL_MISS_LANES) || round + 1u >= PT_TUNE(L.pool_miss_iters, PT_POOL_MISS_ITERS)) break;
                 }
                 if (p != 0xFFFFFFFFu) {
                     if (dirty) {
@@ -1947,7 +2000,11 @@ size_t pt_trace_gstack_bytes(uint32_t n_blocks, uint32_t stack_depth)
 static hipError_t launch_items(const PtTraceParams &p, uint32_t n_blocks, bool overflow, bool detailed_stats, hipStream_t stream)
 {
     const dim3 grid(n_blocks, 1, 1), block(PT_TRACE_BLOCK, 1, 1);
-    static const size_t lds_pad = getenv("PTRT_LDS_PAD") ? (size_t)atoi(getenv("PTRT_LDS_PAD")) : 0;  // tuning aid: lowers occupancy
+#ifdef PT_TUNING
+    static const size_t lds_pad = getenv("PTRT_LDS_PAD") ? (size_t)atoi(getenv("PTRT_LDS_PAD")) : 0;  // lowers occupancy
+#else
+    const size_t lds_pad = 0;
+#endif
 #define PT_LAUNCH(ST, OV, GZ, S1, DI) hipLaunchKernelGGL((trace_kernel<ST, OV, GZ, S1, DI>), grid, block, lds_pad, stream, p)
 #define PT_LAUNCH_DI(OV, DI)                                                  \
     do {                                                                      \

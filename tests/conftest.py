@@ -29,13 +29,10 @@ def megakernel(request):
     if kind is None:
         yield None
         return
-    old = os.environ.get("PTRT_KERNEL")
-    os.environ["PTRT_KERNEL"] = kind  # read by the library at every render call
+    pt = _pkgload.load()
+    pt.force_kernel(kind)  # PT_FLAG_POOL_KERNEL / PT_FLAG_TILE_KERNEL on every Renderer the test makes
     yield kind
-    if old is None:
-        os.environ.pop("PTRT_KERNEL", None)
-    else:
-        os.environ["PTRT_KERNEL"] = old
+    pt.force_kernel(None)
 
 
 def _ensure_built():

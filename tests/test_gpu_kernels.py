@@ -2,8 +2,6 @@
 one-wave-per-tile one (PT_FLAG_TILE_KERNEL, also the fallback for depth 0) -- must produce the same bits:
 sums, primary-hit AOV, ray count and the detailed counters.  The other GPU tests pin each of them to the
 oracle (tests/conftest.py runs every GPU test once per kernel)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -11,12 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def megakernel():
-    """These tests choose the kernel themselves, through the flags."""
-    old = os.environ.pop("PTRT_KERNEL", None)
+def megakernel(pt):
+    """These tests choose the kernel themselves, through the flags (nothing is forced from outside)."""
+    pt.force_kernel(None)
     yield None
-    if old is not None:
-        os.environ["PTRT_KERNEL"] = old
 
 
 def _render(pt, scene, w, h, st, sky, flags, calls):

@@ -1,3 +1,6 @@
+#!/bin/bash
+# the PTRT_* overrides are read by the tuning build only (make -C path-tracer_amd/csrc tuning)
+export PTRT_LIB=${PTRT_LIB:-$PWD/path-tracer_amd/libptrt_tuning.so}
 run() { echo -n "$* -> "; env "$@" timeout -k 10 120 python tools/kernel_choice.py 4 8 12 16 | sed 's/.*triangles= *\([0-9]*\).*per-tile *\([0-9]*\) Mrays.*/\1:\2/' | tr '\n' ' '; echo; }
 export FRAMES=48 SPP=1
 run X=0

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the PTRT_* overrides are read by the tuning build only (make -C path-tracer_amd/csrc tuning)
+export PTRT_LIB=${PTRT_LIB:-$PWD/path-tracer_amd/libptrt_tuning.so}
 # GPU box: sweep the pooled kernel's scheduling knobs (environment overrides) with short bench runs.
 run() { echo -n "$* -> "; env "$@" timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.0f Mrays/s %.2f ms" % (d["value"], d["ms_per_step"]))' || exit 1; }
 run X=0

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the PTRT_* overrides are read by the tuning build only (make -C path-tracer_amd/csrc tuning)
+export PTRT_LIB=${PTRT_LIB:-$PWD/path-tracer_amd/libptrt_tuning.so}
 # GPU box: the pooled kernel's scheduling knobs at several samples per frame (SPP, FRAMES from the environment).
 export SPP=${SPP:-2} FRAMES=${FRAMES:-64}
 run() { echo -n "$* -> "; env "$@" timeout -k 10 120 python tools/kernel_choice.py 76 | sed 's/.*pooled *\([0-9]*\) Mrays.*/\1/' || exit 1; }
