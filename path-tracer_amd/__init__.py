@@ -90,6 +90,7 @@ ABI = [
     ("pt_set_settings", _I, [_VP, _VP]),
     ("pt_render", _I, [_VP, _U32]),
     ("pt_render_frames", _I, [_VP, _U32, _U32, _U32]),
+    ("pt_render_frames_static", _I, [_VP, _U32, _U32, _U32]),
     ("pt_reset", _I, [_VP]),
     ("pt_sync", _I, [_VP]),
     ("pt_read_sum_rgba32f", _I, [_VP, _VP]),
@@ -350,6 +351,10 @@ class Renderer:
 
     def render_frames(self, time0: int, stride: int, n_frames: int):
         self._ck(self._l.pt_render_frames(self._ctx, time0 & 0xFFFFFFFF, stride, n_frames))
+
+    def render_frames_static(self, time0: int, stride: int, n_frames: int):
+        """pt_render_frames without any device allocation (scheduling memory from the library's static array)."""
+        self._ck(self._l.pt_render_frames_static(self._ctx, time0 & 0xFFFFFFFF, stride, n_frames))
 
     def reset_ready_samples(self):
         self._ck(self._l.pt_reset(self._ctx))

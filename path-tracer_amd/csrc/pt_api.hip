@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -75,6 +76,7 @@ struct pt_ctx {
     size_t scratch_bytes = 0;
 
     uint64_t frames = 0;
+    bool last_static = false;  // the last render call took its scheduling memory from the static scratch array
 
     // The plan (item table) of the last planned launch, and what it was made for: an identical launch runs it
     // again instead of planning anew (nothing that decides a tile's cost has changed).
@@ -100,7 +102,36 @@ struct pt_ctx {
     float4 *window_frame = nullptr;   // the frame being rendered (zero between frames)
 };
 
+// ---- static scratch for pt_render_frames_static ---------------------------------------------------------------
+// Work-item table, partial sums and deep-stack spill space of a launch, for callers that cannot allocate (HIP graph
+// capture, serving loops).  One copy per GPU, held from the moment the library's code is loaded onto that GPU until
+// the process ends; every context on a GPU shares it (calls that overlap on one GPU race).  In host code the array's
+// name is only a handle for hipGetSymbolAddress: g_static[device].ptr is the device address to use.
+#define PT_STATIC_SCRATCH_BYTES (192ull << 20)
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+struct StaticScratch {
+    std::mutex lock;
+    unsigned char *ptr = nullptr;     // device address of this GPU's copy of `scratch`
+    const pt_ctx *last_user = nullptr;  // context whose plan the array holds
+} g_static[kMaxDevices];
+
+// Once per device, with that device current (pt_create calls it).
+hipError_t static_scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(g_static[device].lock);
+    if (g_static[device].ptr) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p || (reinterpret_cast<uintptr_t>(p) & 255u)) return hipErrorInvalidSymbol;
+    g_static[device].ptr = static_cast<unsigned char *>(p);
+    return hipSuccess;
+}
 
 thread_local std::string g_create_error;
 
@@ -236,7 +267,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
         return fail(nullptr, PT_ERR_HIP, "pt_create: no HIP device available (%s)", hipGetErrorString(e));
-    if (device < 0 || device >= count) return fail(nullptr, PT_ERR_INVALID, "pt_create: device %d out of range (%d present)", device, count);
+    if (device < 0 || device >= count || device >= kMaxDevices) return fail(nullptr, PT_ERR_INVALID, "pt_create: device %d out of range (%d present)", device, count);
     pt_ctx *ctx = new (std::nothrow) pt_ctx();
     if (!ctx) return fail(nullptr, PT_ERR_NOMEM, "pt_create: out of host memory");
     ctx->device = device;
@@ -249,6 +280,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
             rc = fail(nullptr, he == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "pt_create: %s: %s", what, hipGetErrorString(he));
     };
     step(hipSetDevice(device), "hipSetDevice");
+    if (rc == PT_OK) step(static_scratch_init(device), "address of the static scratch array");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->accum_owned, n * sizeof(float4)), "accumulation buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_prim, n * sizeof(uint32_t)), "aov buffer");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->aov_t, n * sizeof(float)), "aov buffer");
@@ -286,6 +318,10 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
 void pt_destroy(pt_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->device >= 0 && ctx->device < kMaxDevices) {
+        std::lock_guard<std::mutex> g(g_static[ctx->device].lock);
+        if (g_static[ctx->device].last_user == ctx) g_static[ctx->device].last_user = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
@@ -529,9 +565,34 @@ int pt_set_settings(pt_ctx *ctx, const void *settings16)
     return PT_OK;
 }
 
-int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames)
+// pt_render_frames and pt_render_frames_static: the same launches; `use_static` takes the work-item table, the
+// partial sums and the deep-stack spill space from this GPU's static scratch array instead of context-owned
+// allocations that grow on demand.
+static int render_frames_impl(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames, bool use_static)
 {
     PT_ENTER(ctx);
+    if (use_static && ctx->window_size) return fail(ctx, PT_ERR_STATE, "pt_render_frames_static: not available while a window is set (pt_set_window)");
+    // A plan is run again only if its table is still where and what it was: not across a change of entry point, and
+    // in the static array not after another context's call.
+    unsigned char *static_base = nullptr;
+    size_t static_used = 0;
+    if (use_static) {
+        StaticScratch &ss = g_static[ctx->device];
+        std::lock_guard<std::mutex> g(ss.lock);
+        if (!ss.ptr) return fail(ctx, PT_ERR_STATE, "pt_render_frames_static: the static scratch array has no address on device %d", ctx->device);
+        static_base = ss.ptr;
+        if (ss.last_user != ctx) ctx->scene_generation++;
+        ss.last_user = ctx;
+    }
+    if (ctx->last_static != use_static) ctx->scene_generation++;
+    ctx->last_static = use_static;
+    // bump allocation inside the static array (256-byte granules); null when the array is too small
+    auto carve = [&](size_t bytes) -> void * {
+        const size_t at = (static_used + 255u) & ~(size_t)255u;
+        if (bytes > PT_STATIC_SCRATCH_BYTES || at > PT_STATIC_SCRATCH_BYTES - bytes) return nullptr;
+        static_used = at + bytes;
+        return static_base + at;
+    };
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "pt_render: no camera set");
     if (n_frames == 0) return PT_OK;
     if (ctx->settings.samples_per_pixel == 0) return fail(ctx, PT_ERR_INVALID, "pt_render: samples_per_pixel is 0 (the shader would divide by zero)");
@@ -595,12 +656,18 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     use_pool = use_pool && pool_possible;
     // spill space for traversal stacks deeper than the kernels keep in LDS
     const size_t pgs = use_pool ? pt_pool_gstack_bytes(ctx->n_cus, ctx->bvh_depth) : 0;
-    if (pgs > ctx->pool_gstack_bytes) {
+    uint32_t *pool_gstack = ctx->pool_gstack;
+    if (use_static) {
+        pool_gstack = pgs ? static_cast<uint32_t *>(carve(pgs)) : nullptr;
+        if (pgs && !pool_gstack)
+            return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space, beyond the %llu-byte static scratch", ctx->bvh_depth, pgs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+    } else if (pgs > ctx->pool_gstack_bytes) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         dev_free(ctx->pool_gstack);
         ctx->pool_gstack_bytes = 0;
         PT_HIP(ctx, hipMalloc((void **)&ctx->pool_gstack, pgs));
         ctx->pool_gstack_bytes = pgs;
+        pool_gstack = ctx->pool_gstack;
     }
     // Slots that must be ready before a wave runs a shading pass.  Per-tile kernel: long walks (big meshes)
     // favour shading early, short ones favour full passes (Cornell: 43 vs 37 Grays/s).  Pooled kernel: half a
@@ -634,7 +701,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     if (env_str("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
     sch.use_pool = use_pool;
     sch.next_item = ctx->next_item;
-    sch.pool_gstack = ctx->pool_gstack;
+    sch.pool_gstack = pool_gstack;
     sch.n_cus = ctx->n_cus;
     sch.pool_groups = env_u32("PTRT_POOL_GROUPS", 0);
     p.pool_start = env_u32("PTRT_POOL_START", PT_POOL_START);  // (the kernel reads these in tuning builds only)
@@ -687,6 +754,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         return PT_OK;
     }
 
+    const size_t static_mark = static_used;  // every batch carves its tables from here
     uint32_t done = 0;
     while (done < n_frames) {
         const uint32_t batch = std::min(n_frames - done, max_frames);
@@ -697,15 +765,28 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
         if (batch < regroup_frames && !env_str("PTRT_MAX_CHUNK")) {
             bs.max_chunk = 1;
             bs.min_chunk = 1;
-            // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: not beyond 2 GiB
+            // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: above the
+            // limit the frames run one after the other, one item per tile, with no such rows at all
             const uint64_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
             const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->bvh_depth));
-            if (bytes > (2ull << 30)) bs.min_planned_frames = regroup_frames;  // frame after frame, one item per tile
+            const uint64_t limit = use_static ? PT_STATIC_SCRATCH_BYTES - static_mark - 4096u : PT_SHORT_LAUNCH_SCRATCH_LIMIT;
+            if (bytes > limit) bs.min_planned_frames = regroup_frames;  // frame after frame, one item per tile
         }
+        uint4 *items = ctx->items;
+        float4 *partial = ctx->partial;
+        uint32_t item_cap = ctx->item_cap;
+        static_used = static_mark;
         if (batch >= bs.min_planned_frames) {
             const uint32_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
             blocks = std::max(blocks, cap);
-            if (cap > ctx->item_cap) {
+            if (use_static) {
+                items = static_cast<uint4 *>(carve((size_t)cap * sizeof(uint4)));
+                partial = static_cast<float4 *>(carve((size_t)cap * 64u * sizeof(float4)));
+                item_cap = cap;
+                if (!items || !partial)
+                    return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a launch of %u frames of %u x %u pixels plans up to %u work items (%zu bytes of table and partial sums), beyond the %llu-byte static scratch; render fewer frames per call",
+                                batch, ctx->width, ctx->height, cap, (size_t)cap * (64u * sizeof(float4) + sizeof(uint4)), (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+            } else if (cap > ctx->item_cap) {
                 PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 dev_free(ctx->items);
                 dev_free(ctx->partial);
@@ -714,6 +795,9 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
                 PT_HIP(ctx, hipMalloc((void **)&ctx->partial, (size_t)cap * 64u * sizeof(float4)));
                 ctx->item_cap = cap;
                 ctx->scene_generation++;  // the old plan went with the old table
+                items = ctx->items;
+                partial = ctx->partial;
+                item_cap = cap;
             }
             pt_ctx::PlanKey key;
             key.generation = ctx->scene_generation;
@@ -741,16 +825,21 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
                 ctx->plans_for_key = 1;
             }
         }
-        bs.items = ctx->items;
-        bs.partial = ctx->partial;
-        bs.item_cap = ctx->item_cap;
+        bs.items = items;
+        bs.partial = partial;
+        bs.item_cap = item_cap;
         // spill space for traversal stacks deeper than the per-tile kernel keeps in LDS
         const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->bvh_depth);
-        if (gs) {
+        p.gstack = ctx->gstack;
+        if (gs && use_static) {
+            p.gstack = static_cast<uint32_t *>(carve(gs));
+            if (!p.gstack)
+                return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space for this launch, beyond what is left of the %llu-byte static scratch", ctx->bvh_depth, gs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+        } else if (gs) {
             int rc = ensure_gstack(ctx, gs);
             if (rc != PT_OK) return rc;
+            p.gstack = ctx->gstack;
         }
-        p.gstack = ctx->gstack;
         p.gstack_cap = gs ? ctx->bvh_depth : 0;
         p.gstack_blocks = gs ? blocks : 0;
         PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
@@ -761,6 +850,10 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
     }
     return PT_OK;
 }
+
+int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames) { return render_frames_impl(ctx, time0, stride, n_frames, false); }
+
+int pt_render_frames_static(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames) { return render_frames_impl(ctx, time0, stride, n_frames, true); }
 
 int pt_render(pt_ctx *ctx, uint32_t time) { return pt_render_frames(ctx, time, 0, 1); }
 

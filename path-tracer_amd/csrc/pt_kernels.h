@@ -31,6 +31,10 @@
 #define PT_POOL_MULTI_MIN_FRAMES 16u
 #define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
+// Launches of 2..15 frames plan one work item (a 1 KiB row of partial sums) per tile and frame so that the frames
+// run side by side; above this many bytes of such rows they run frame after frame instead (one item per tile, no
+// rows), which costs time but no memory.
+#define PT_SHORT_LAUNCH_SCRATCH_LIMIT (640ull << 20)
 #define PT_PLAN_REUSE_PERIOD 8u  // pooled kernel, identical launches: of 8, six run the old plan, one also measures, one plans anew
 // pooled kernel: scheduling thresholds (see PtTraceParams for what each one means)
 #define PT_POOL_START 32u
