@@ -91,3 +91,90 @@ def test_1080p_several_samples_per_frame_match_oracle(pt, po, scenes):
     assert r.stats()["rays"] == rays and (got[..., 3] == n + 1).all()
     np.testing.assert_allclose(got, want, rtol=(n + 1) * 2.0 ** -23, atol=1e-6)
     r.close()
+
+
+def test_bunny_4k_frames_match_oracle(pt, po, scenes):
+    """BASELINE configs[3] on one GPU: a 3840x2160 dispatch bit-exact (radiance, primary-hit ids and t, ray count), then
+    a 16-frame launch planned into work items: ray count exact, sums equal up to summation order."""
+    scene, w, h, st, frames, sky = _config(pt, scenes, "bunny_4k_d8_spp4096", 256)
+    assert (w, h, st.samples_per_pixel, st.depth, frames) == (3840, 2160, 1, 8, 4096)
+    osc = po.from_scene(scene, w, h, st, sky)
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV)
+    r.set_sky_cube(sky)
+    r.render(1)
+    want, prim, tt, ost = osc.render(1, want_aov=True)
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim)
+    _exact(gt, tt, "primary-hit t")
+    _exact(r.read_sum(), want, "one 4K frame")
+    assert r.stats()["rays"] == ost["rays"]
+    n, rays = 16, ost["rays"]
+    r.render_frames(4000, 1, n)
+    for f in range(n):
+        want, _, _, ost = osc.render(4000 + f, want)
+        rays += ost["rays"]
+    got = r.read_sum()
+    assert r.stats()["rays"] == rays and (got[..., 3] == n + 1).all()
+    np.testing.assert_allclose(got, want, rtol=(n + 1) * 2.0 ** -23, atol=1e-6)
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def field(pt, po, scenes):
+    """BASELINE configs[4]: the 9 980 928-triangle instanced field, built once for both kernels; the oracle's own
+    builder must give the same 12.4 M nodes and the same index permutation as the library's threaded one."""
+    factory, w, h, st, frames = scenes.CONFIGS["field_4k_d8_spp1024"]
+    assert (w, h, st.samples_per_pixel, st.depth, frames) == (3840, 2160, 1, 8, 1024)
+    scene = factory()
+    nodes, idx = po.bvh_build(scene.triangles)
+    assert np.array_equal(nodes.view(np.uint8), scene.nodes.view(np.uint8)) and np.array_equal(idx, scene.triangle_indices)
+    # depth of the deepest node, level by level over the oracle's nodes
+    depth, level = 0, np.zeros(1, np.int64)
+    while True:
+        inner = level[nodes["count"][level] == 0]
+        if inner.size == 0:
+            break
+        left = nodes["left"][inner].astype(np.int64)
+        level = np.concatenate([left, left + 1])
+        depth += 1
+    return scene, nodes, idx, depth, w, h, st
+
+
+def test_field_4k_frame_matches_oracle(pt, po, scenes, field):
+    """One full-resolution dispatch of the 10 M-triangle scene (tree deeper than either kernel's on-chip stack, leaf
+    tokens with 24-bit slot numbers): radiance, primary-hit ids and t bit-exact, ray count and tree depth equal."""
+    scene, nodes, idx, depth, w, h, st = field
+    assert len(scene.triangles) == 9980928 and depth > 24
+    sky = scenes.sky_cube_direct(64)
+    osc = po.OracleScene(w, h, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), scene.triangles, nodes, idx, sky)
+    r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV)
+    r.set_sky_cube(sky)
+    r.render(1)
+    want, prim, tt, ost = osc.render(1, want_aov=True)
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim) and int((prim < 0x80000000).sum()) > 1000000
+    _exact(gt, tt, "primary-hit t")
+    _exact(r.read_sum(), want, "one 4K frame of the field")
+    s = r.stats()
+    assert s["rays"] == ost["rays"] and s["bvh_depth"] == depth and ost["max_stack"] <= depth
+    r.close()
+
+
+def test_field_planned_launch_matches_oracle(pt, po, scenes, field):
+    """The same scene in a 16-frame planned launch at 960x540 (the stacks spill to global memory in planned launches
+    too): ray count exact, sums equal up to summation order."""
+    scene, nodes, idx, depth, _, _, st = field
+    w, h, n = 960, 540, 16
+    sky = scenes.sky_cube_direct(64)
+    osc = po.OracleScene(w, h, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), scene.triangles, nodes, idx, sky)
+    r = pt.Renderer(scene, w, h, settings=st)
+    r.set_sky_cube(sky)
+    r.render_frames(1, 1, n)
+    want, rays = np.zeros((h, w, 4), np.float32), 0
+    for f in range(n):
+        want, _, _, ost = osc.render(1 + f, want)
+        rays += ost["rays"]
+    got = r.read_sum()
+    assert r.stats()["rays"] == rays and (got[..., 3] == n).all()
+    np.testing.assert_allclose(got, want, rtol=n * 2.0 ** -23, atol=1e-6)
+    r.close()
