@@ -2,33 +2,42 @@
 """Benchmark of the path-tracing hot path on MI355X.
 
 Metric: Mrays/s, 1 ray = 1 hitScene call (compute.wgsl:138), counted by the kernel itself.
-Workload (BASELINE.json configs[2]): ~69k-triangle mesh + ground sphere, 1920x1080, 8 bounces,
+Default workload (BASELINE.json configs[2]): ~69k-triangle mesh + ground sphere, 1920x1080, 8 bounces,
 256 spp rendered as 256 dispatch-equivalents of 1 spp fused into one launch, sky = 4096^2 cube
-map generated on the GPU from a procedural panorama.  One "step" = that whole 256-spp job on
-every rank: clear the accumulation buffer, one launch of the megakernel, and (N > 1) one RCCL
-sum-reduce of the fp32 accumulation buffers to rank 0.  Rank g of G renders the frames with
-time = time0 + g + i*G, so the reduced image is the (256*G)-spp image: weak scaling.
+map generated on the GPU from a procedural panorama.  One "step" = that whole job on every rank:
+clear the accumulation buffer, one launch of the megakernel, and (N > 1) one RCCL sum-reduce of the
+fp32 accumulation buffers to rank 0.
 
-Usage: python bench.py [--gpus N --steps K --warmup W] [--workload NAME] [--no-cpu-baseline]
-Multi-GPU: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Scaling over N GPUs (frames are independent given their time value, compute.wgsl:85; rank g renders the
+frames f = g (mod N) of the step's frame range):
+  weak   (default)  every rank renders the configuration's frame count: the reduced image has N times the samples;
+  strong            the configuration's frame count is dealt over the ranks (BASELINE configs[3]: 4096 spp split
+                    across 2/4/8 GPUs): fixed total work.
+
+Usage: python bench.py [--gpus N --steps K --warmup W] [--workload NAME] [--scaling weak|strong] [--no-cpu-baseline]
+With --gpus N > 1 and no torch.distributed environment the script starts its own N worker processes
+(python -m torch.distributed.run on 127.0.0.1) and relays rank 0's JSON line; under an external
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import importlib
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import _pkgload  # noqa: E402
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak (packed issue), spec
 HBM_PEAK_GBS = 8000.0
+DEFAULT_SCALING = {"bunny_4k_d8_spp4096": "strong", "field_4k_d8_spp1024": "strong"}
 
 
 def algorithmic_flops(st: dict) -> float:
@@ -46,14 +55,60 @@ def algorithmic_bytes(st: dict, pixel_frames: int) -> float:
             + 32.0 * pixel_frames)
 
 
-def build_workload(pt, scenes, name: str):
-    factory, w, h, settings, frames = scenes.CONFIGS[name]
-    return factory(), w, h, settings, frames
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="bunny_1080p_d8_spp256")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong for the configurations BASELINE.json splits across GPUs, weak otherwise")
+    ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
+    ap.add_argument("--sky-size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
+
+
+def self_launch_command(args, argv, port: int) -> list[str]:
+    """The worker launch of `python bench.py --gpus N` when no torch.distributed environment is present."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def frames_of_step(multi, rank: int, world: int, scaling: str, frames: int, step: int):
+    """(time0, stride, count) of this rank's frames in step `step`; steps use disjoint time ranges."""
+    total = frames * world if scaling == "weak" else frames
+    return multi.frames_for_rank(rank, world, 1 + step * total, total)
+
+
+def find_traffic(workload: str, frames_per_launch: int):
+    """HBM bytes per launch from the newest committed PMC record of this workload and launch length
+    (profiles/rNN/<anything>/pmc_traffic.json, written by tools/summarize_prof.py)."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "**", "pmc_traffic.json"), recursive=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("workload") != workload or rec.get("frames") != frames_per_launch:
+            continue
+        m = re.search(r"profiles/r(\d+)/", path.replace(os.sep, "/"))
+        key = (int(m.group(1)) if m else 0, os.path.getmtime(path))
+        if best is None or key > best[0]:
+            best = (key, rec, os.path.relpath(path, ROOT))
+    return (best[1].get("hbm_bytes_per_launch"), best[2]) if best else (None, None)
 
 
 def cpu_baseline(pt, scenes, scene, w, h, settings, sky_cube, budget_s: float = 20.0):
     """Times the CPU oracle (a scalar C port of the shader, NOT lavapipe) on a bounded sample of
     the same workload: whole 1-spp frames at full resolution until ~budget_s is used."""
+    import numpy as np
     from oracle import pt_oracle as po
     cores = min(os.cpu_count() or 1, 16)
     osc = po.from_scene(scene, w, h, settings, sky_cube)
@@ -67,29 +122,27 @@ def cpu_baseline(pt, scenes, scene, w, h, settings, sky_cube, budget_s: float = 
         if dt > budget_s or dt * (frames + 1) / frames > 1.25 * budget_s:
             break
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full-resolution 1-spp frames of the same scene ({rays} rays, {dt:.1f} s); "
+            "sample": f"{frames} full-resolution {settings.samples_per_pixel}-spp frames of the same scene ({rays} rays, {dt:.1f} s); "
                       f"oracle/pt_oracle.c, gcc -O2 -ffp-contract=off, pthreads"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="bunny_1080p_d8_spp256")
-    ap.add_argument("--frames", type=int, default=0, help="override frames per step (default: the config's spp)")
-    ap.add_argument("--sky-size", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Nothing in this process has touched the GPU yet: start the ranks as children and pass their output through.
+        cmd = self_launch_command(args, sys.argv[1:], free_port())
+        sys.exit(subprocess.run(cmd).returncode)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
+    import _pkgload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -100,9 +153,11 @@ def main():
     pt = _pkgload.load()
     scenes = importlib.import_module("path_tracer_amd.scenes")
     multi = importlib.import_module("path_tracer_amd.multi")
-    scene, w, h, settings, frames = build_workload(pt, scenes, args.workload)
+    factory, w, h, settings, frames = scenes.CONFIGS[args.workload]
+    scene = factory()
     if args.frames:
         frames = args.frames
+    scaling = args.scaling or DEFAULT_SCALING.get(args.workload, "weak")
 
     # the renderer accumulates straight into a torch tensor so RCCL can reduce it in place
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
@@ -113,9 +168,13 @@ def main():
     pano = scenes.sky_equirect(pano_w, pano_w // 2)
     r.set_sky_equirect(pano, args.sky_size)
 
-    def step(i: int):
+    def step(i: int, events=None):
         accum.zero_()
-        r.render_frames(*multi.frames_for_rank(rank, world, 1 + i * frames * world, frames * world))
+        if events:
+            events[0].record(stream)
+        r.render_frames(*frames_of_step(multi, rank, world, scaling, frames, i))
+        if events:
+            events[1].record(stream)
         if world > 1:
             multi.reduce_sum_to_root(accum, 0)
 
@@ -126,19 +185,14 @@ def main():
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
-        step(-1 - i)
+        step(args.steps + i)
     fence()
     rays_before = r.stats()["rays"]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        accum.zero_()
-        ev[i][0].record(stream)
-        r.render_frames(*multi.frames_for_rank(rank, world, 1 + i * frames * world, frames * world))
-        ev[i][1].record(stream)
-        if world > 1:
-            multi.reduce_sum_to_root(accum, 0)
+        step(i, ev[i])
     fence()
     elapsed = time.perf_counter() - t0
     rays = r.stats()["rays"] - rays_before
@@ -151,54 +205,56 @@ def main():
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
     elapsed_max, rays_total = float(tt.item()), float(rr.item())
 
-    out = None
     if rank == 0:
-        # algorithmic work of ONE launch, counted by the detailed-stats build of the same kernel on the
+        # algorithmic work of ONE launch of this rank, counted by the detailed-stats build of the same kernel on the
         # same frames (untimed), priced with the work model above
+        launch = frames_of_step(multi, rank, world, scaling, frames, 0)
         r.set_flags(pt.PT_FLAG_DETAILED_STATS)
         r.reset_ready_samples()
-        r.render_frames(*multi.frames_for_rank(rank, world, 1, frames * world))
+        r.render_frames(*launch)
         st = r.stats()
         r.set_flags(0)
-        flops, abytes = algorithmic_flops(st), algorithmic_bytes(st, w * h * frames)
+        flops, abytes = algorithmic_flops(st), algorithmic_bytes(st, w * h * launch[2])
         k_ms = float(np.mean(kernel_ms))
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath))
-                if rec.get("workload") == args.workload and rec.get("frames") == frames:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        k_s = k_ms * 1e-3
+        valu_tflops = flops / k_s / 1e12
+        valu_frac = valu_tflops / FP32_VALU_PEAK_TFLOPS
+        traffic, traffic_src = find_traffic(args.workload, launch[2])
+        hbm_gbs = traffic / k_s / 1e9 if traffic else None
+        hbm_frac = hbm_gbs / HBM_PEAK_GBS if traffic else None
+        # The bound is the roof the launch sits closer to.  HBM: measured bytes (PMC, per launch) over the launch time --
+        # the algorithmic bytes below are mostly served by L2 / Infinity Cache and overstate what HBM has to deliver.
+        if hbm_frac is not None and hbm_frac > valu_frac:
+            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
+        else:
+            roof = {"bound": "valu", "achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+        roof.update({
+            "traffic": traffic, "traffic_source": traffic_src,
+            "valu_frac": valu_frac, "valu_TFLOPs": valu_tflops, "hbm_frac": hbm_frac, "hbm_traffic_GBps": hbm_gbs,
+            "kernel": "pool_kernel (+ accumulate_kernel; plan_kernel in two launches of every eight)" if r_uses_pool(pt, scene, settings, launch[2])
+                      else "trace_kernel (+ plan_kernel and accumulate_kernel)",
+            "kernel_ms": k_ms, "frames_per_launch": launch[2], "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": abytes, "algorithmic_GBps": abytes / k_s / 1e9,
+            "note": "no MFMA: nothing here is a dense contraction; valu_frac prices the shader's own flop count against the packed-FP32 "
+                    "vector peak, hbm_frac the measured HBM bytes of one launch against 8 TB/s (null until a PMC record of this "
+                    "workload and launch length is committed under profiles/)"})
         out = {
             "metric": "Mrays/s, bunny 1080p 8-bounce, 1/2/4/8 GPUs; % FP32 VALU peak",
             "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "depth": settings.depth,
-                       "spp_per_gpu_per_step": frames * settings.samples_per_pixel, "triangles": int(len(scene.triangles)),
+                       "spp_per_step": (frames * world if scaling == "weak" else frames) * settings.samples_per_pixel,
+                       "spp_per_gpu_per_step": launch[2] * settings.samples_per_pixel, "triangles": int(len(scene.triangles)),
                        "bvh_nodes": int(len(scene.nodes)), "bvh_depth": st["bvh_depth"], "sky_cube": args.sky_size,
-                       "rays_per_step_per_gpu": rays // max(args.steps, 1),
-                       "parallelism": f"sample-split x{world}, one RCCL sum-reduce per step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "pool_kernel for this workload (library default for meshes >= 8192 triangles in launches >= 48 samples per pixel "
-                                   "and smaller meshes in launches >= 192; trace_kernel otherwise), + accumulate_kernel; plan_kernel and the per-tile cost "
-                                   "measurement run in the first two launches of a configuration (warm-up) and then in two of every eight; the other "
-                                   "identical launches reuse the work-item table; a 4-frame probe launch in the very first step",
-                         "kernel_ms": k_ms, "flops_per_launch": flops,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "algorithmic_GBps": abytes / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-                         "hbm_traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "note": "VALU-bound traversal: no MFMA (nothing is a dense contraction); working set "
-                                 "is L2/Infinity-Cache resident, so the HBM figure is informational"},
+                       "rays_per_step": int(rays_total) // max(args.steps, 1),
+                       "parallelism": f"sample-split x{world} ({scaling}), one RCCL sum-reduce per step" if world > 1 else "single GPU"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sky_cube = r.read_sky_cube(args.sky_size)
+            sky_cube = r.read_sky_cube()
             out["cpu_baseline"] = cpu_baseline(pt, scenes, scene, w, h, settings, sky_cube)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         else:
@@ -208,6 +264,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def r_uses_pool(pt, scene, settings, frames_per_launch: int) -> bool:
+    """Mirror of the library's kernel choice (pt_kernels.h: PT_POOL_*), for the roofline block's label only."""
+    tris, spp = len(scene.triangles), max(settings.samples_per_pixel, 1)
+    samples = frames_per_launch * spp
+    if spp == 1:
+        return (tris >= 8192 and frames_per_launch >= 48) or (tris >= 512 and frames_per_launch >= 192)
+    return (tris >= 8192 and samples >= 48 and (frames_per_launch == 1 or frames_per_launch >= 16)) or \
+           (tris >= 2048 and samples >= 192 and frames_per_launch >= 16)
 
 
 if __name__ == "__main__":

@@ -100,8 +100,9 @@ int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size);
 /* Same, but runs the equirectangular->cube kernel (shaders/equirectangular.wgsl:12-81) on the GPU
  * from a decoded w x h RGBA32F panorama (texture.rs:179-188). */
 int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size);
-/* Copies the current cube map back to the host (6*size*size*4 floats). */
-int pt_read_sky_cube(pt_ctx *ctx, float *out);
+/* Copies the current cube map back to the host (6*size*size*4 floats; fewer than that in capacity_floats is
+ * PT_ERR_INVALID).  *size (may be NULL) receives the face size, 0 without a sky; with out == NULL only that. */
+int pt_read_sky_cube(pt_ctx *ctx, float *out, size_t capacity_floats, uint32_t *size);
 
 /* ---- per-frame uniforms: Renderer::update_buffers (renderer.rs:518-548) ------------ */
 int pt_set_camera(pt_ctx *ctx, const void *camera64);

@@ -84,7 +84,7 @@ ABI = [
     ("pt_set_mesh", _I, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
     ("pt_set_sky_cube", _I, [_VP, _VP, _U32]),
     ("pt_set_sky_equirect", _I, [_VP, _VP, _U32, _U32, _U32]),
-    ("pt_read_sky_cube", _I, [_VP, _VP]),
+    ("pt_read_sky_cube", _I, [_VP, _VP, C.c_size_t, C.POINTER(_U32)]),
     ("pt_set_camera", _I, [_VP, _VP]),
     ("pt_set_spheres", _I, [_VP, _VP]),
     ("pt_set_settings", _I, [_VP, _VP]),
@@ -327,11 +327,13 @@ class Renderer:
         pano = np.ascontiguousarray(pano, np.float32)
         assert pano.ndim == 3 and pano.shape[2] == 4
         self._ck(self._l.pt_set_sky_equirect(self._ctx, _ptr(pano), pano.shape[1], pano.shape[0], cube_size))
-        self._sky_size = cube_size
 
-    def read_sky_cube(self, size: int) -> np.ndarray:
-        out = np.zeros((6, size, size, 4), np.float32)
-        self._ck(self._l.pt_read_sky_cube(self._ctx, _ptr(out)))
+    def read_sky_cube(self) -> np.ndarray:
+        size = C.c_uint32(0)
+        self._ck(self._l.pt_read_sky_cube(self._ctx, None, 0, C.byref(size)))
+        out = np.zeros((6, size.value, size.value, 4), np.float32)
+        if size.value:
+            self._ck(self._l.pt_read_sky_cube(self._ctx, _ptr(out), out.size, C.byref(size)))
         return out
 
     def update_scene(self, scene: Scene):

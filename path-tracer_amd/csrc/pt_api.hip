@@ -147,6 +147,26 @@ int fail(pt_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+// for the catch-all guards: a message short enough for the string's in-place buffer, so that reporting an
+// allocation failure does not allocate
+int fail_static(pt_ctx *ctx, int code, const char *msg) noexcept
+{
+    try {
+        if (ctx) ctx->err.assign(msg);
+        else g_create_error.assign(msg);
+    } catch (...) {
+    }
+    return code;
+}
+
+// The calling thread's current device is put back when an entry point returns (a host that drives several GPUs
+// from one thread must not find its later allocations redirected to the context's device).
+struct DeviceGuard {
+    int saved = -1;
+    explicit DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 #define PT_HIP(ctx, call)                                                                              \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
@@ -155,11 +175,10 @@ int fail(pt_ctx *ctx, int code, const char *fmt, ...)
                         hipGetErrorString(e_));                                                        \
     } while (0)
 
-#define PT_ENTER(ctx)                                                    \
-    do {                                                                 \
-        if (!(ctx)) return fail(nullptr, PT_ERR_INVALID, "null context"); \
-        PT_HIP(ctx, hipSetDevice((ctx)->device));                        \
-    } while (0)
+#define PT_ENTER(ctx)                                                 \
+    if (!(ctx)) return fail(nullptr, PT_ERR_INVALID, "null context"); \
+    DeviceGuard device_guard_;                                        \
+    PT_HIP(ctx, hipSetDevice((ctx)->device))
 
 template <typename T>
 int dev_alloc(pt_ctx *ctx, T **p, size_t count)
@@ -257,10 +276,11 @@ extern "C" {
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
+static int pt_create_impl(int device, uint32_t width, uint32_t height, pt_ctx **out)
 {
     if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: null output pointer");
     *out = nullptr;
+    DeviceGuard device_guard_;
     if (width == 0 || height == 0) return fail(nullptr, PT_ERR_INVALID, "pt_create: zero image size");
     if ((uint64_t)width * height > (1ull << 30)) return fail(nullptr, PT_ERR_LIMIT, "pt_create: image larger than 2^30 pixels");
     int count = 0;
@@ -318,6 +338,7 @@ int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
 void pt_destroy(pt_ctx *ctx)
 {
     if (!ctx) return;
+    DeviceGuard device_guard_;
     if (ctx->device >= 0 && ctx->device < kMaxDevices) {
         std::lock_guard<std::mutex> g(g_static[ctx->device].lock);
         if (g_static[ctx->device].last_user == ctx) g_static[ctx->device].last_user = nullptr;
@@ -346,7 +367,7 @@ void pt_destroy(pt_ctx *ctx)
     delete ctx;
 }
 
-int pt_set_stream(pt_ctx *ctx, void *hip_stream)
+static int pt_set_stream_impl(pt_ctx *ctx, void *hip_stream)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -354,7 +375,7 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream)
     return PT_OK;
 }
 
-int pt_set_flags(pt_ctx *ctx, uint32_t flags)
+static int pt_set_flags_impl(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
@@ -363,7 +384,7 @@ int pt_set_flags(pt_ctx *ctx, uint32_t flags)
     return PT_OK;
 }
 
-int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
+static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
@@ -466,7 +487,7 @@ int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *no
     return PT_OK;
 }
 
-int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size)
+static int pt_set_sky_cube_impl(pt_ctx *ctx, const float *rgba32f, uint32_t size)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -489,7 +510,7 @@ int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size)
     return PT_OK;
 }
 
-int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size)
+static int pt_set_sky_equirect_impl(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -513,17 +534,20 @@ int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t 
     return PT_OK;
 }
 
-int pt_read_sky_cube(pt_ctx *ctx, float *out)
+static int pt_read_sky_cube_impl(pt_ctx *ctx, float *out, size_t capacity_floats, uint32_t *size)
 {
     PT_ENTER(ctx);
-    if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_sky_cube: null output");
+    if (size) *size = ctx->sky_size;
+    if (!out) return size ? PT_OK : fail(ctx, PT_ERR_INVALID, "pt_read_sky_cube: null output");
     if (!ctx->sky_size) return fail(ctx, PT_ERR_STATE, "pt_read_sky_cube: no sky set");
+    const size_t need = 6 * (size_t)ctx->sky_size * ctx->sky_size * 4;
+    if (capacity_floats < need) return fail(ctx, PT_ERR_INVALID, "pt_read_sky_cube: room for %zu floats, the %u^2 cube has %zu", capacity_floats, ctx->sky_size, need);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PT_HIP(ctx, hipMemcpy(out, ctx->sky, 6 * (size_t)ctx->sky_size * ctx->sky_size * sizeof(float4), hipMemcpyDeviceToHost));
+    PT_HIP(ctx, hipMemcpy(out, ctx->sky, need * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
-int pt_set_camera(pt_ctx *ctx, const void *camera64)
+static int pt_set_camera_impl(pt_ctx *ctx, const void *camera64)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
@@ -533,7 +557,7 @@ int pt_set_camera(pt_ctx *ctx, const void *camera64)
     return PT_OK;
 }
 
-int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
+static int pt_set_spheres_impl(pt_ctx *ctx, const void *sphere_data8208)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
@@ -556,7 +580,7 @@ int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
     return PT_OK;
 }
 
-int pt_set_settings(pt_ctx *ctx, const void *settings16)
+static int pt_set_settings_impl(pt_ctx *ctx, const void *settings16)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
@@ -568,7 +592,7 @@ int pt_set_settings(pt_ctx *ctx, const void *settings16)
 // pt_render_frames and pt_render_frames_static: the same launches; `use_static` takes the work-item table, the
 // partial sums and the deep-stack spill space from this GPU's static scratch array instead of context-owned
 // allocations that grow on demand.
-static int render_frames_impl(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames, bool use_static)
+static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames, bool use_static)
 {
     PT_ENTER(ctx);
     if (use_static && ctx->window_size) return fail(ctx, PT_ERR_STATE, "pt_render_frames_static: not available while a window is set (pt_set_window)");
@@ -851,13 +875,24 @@ static int render_frames_impl(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint
     return PT_OK;
 }
 
+static int render_frames_impl(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames, bool use_static)
+{
+    try {
+        return render_frames_unguarded(ctx, time0, stride, n_frames, use_static);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+
 int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames) { return render_frames_impl(ctx, time0, stride, n_frames, false); }
 
 int pt_render_frames_static(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames) { return render_frames_impl(ctx, time0, stride, n_frames, true); }
 
 int pt_render(pt_ctx *ctx, uint32_t time) { return pt_render_frames(ctx, time, 0, 1); }
 
-int pt_reset(pt_ctx *ctx)
+static int pt_reset_impl(pt_ctx *ctx)
 {
     PT_ENTER(ctx);
     const size_t n = (size_t)ctx->width * ctx->height;
@@ -886,14 +921,14 @@ int check_gave_up(pt_ctx *ctx)
 }
 }  // namespace
 
-int pt_sync(pt_ctx *ctx)
+static int pt_sync_impl(pt_ctx *ctx)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return check_gave_up(ctx);
 }
 
-int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
+static int pt_read_sum_rgba32f_impl(pt_ctx *ctx, float *out)
 {
     PT_ENTER(ctx);
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_sum_rgba32f: null output");
@@ -902,7 +937,7 @@ int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
     return check_gave_up(ctx);
 }
 
-int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
+static int pt_read_mean_rgba32f_impl(pt_ctx *ctx, float *out)
 {
     PT_ENTER(ctx);
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_mean_rgba32f: null output");
@@ -915,7 +950,7 @@ int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
     return check_gave_up(ctx);
 }
 
-int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
+static int pt_read_rgba8_impl(pt_ctx *ctx, uint8_t *out)
 {
     PT_ENTER(ctx);
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_read_rgba8: null output");
@@ -928,7 +963,7 @@ int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
     return check_gave_up(ctx);
 }
 
-int pt_set_window(pt_ctx *ctx, uint32_t sample_size)
+static int pt_set_window_impl(pt_ctx *ctx, uint32_t sample_size)
 {
     PT_ENTER(ctx);
     if (sample_size > 256u) return fail(ctx, PT_ERR_LIMIT, "pt_set_window: sample_size %u exceeds MAX_NUMBER_OF_SAMPLES (256)", sample_size);
@@ -956,7 +991,7 @@ int pt_set_window(pt_ctx *ctx, uint32_t sample_size)
     return PT_OK;
 }
 
-int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown)
+static int pt_read_window_impl(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown)
 {
     PT_ENTER(ctx);
     if (!ctx->window_size) return fail(ctx, PT_ERR_STATE, "pt_read_window: no window (pt_set_window)");
@@ -978,7 +1013,7 @@ int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t
     return check_gave_up(ctx);
 }
 
-int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
+static int pt_read_aov_impl(pt_ctx *ctx, uint32_t *prim, float *t)
 {
     PT_ENTER(ctx);
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -988,7 +1023,7 @@ int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
     return PT_OK;
 }
 
-int pt_stats(pt_ctx *ctx, pt_stats_t *out)
+static int pt_stats_impl(pt_ctx *ctx, pt_stats_t *out)
 {
     PT_ENTER(ctx);
     if (!out) return fail(ctx, PT_ERR_INVALID, "pt_stats: null output");
@@ -1015,7 +1050,7 @@ int pt_stats(pt_ctx *ctx, pt_stats_t *out)
 
 void *pt_accum_device_ptr(pt_ctx *ctx) { return ctx ? ctx->accum : nullptr; }
 
-int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
+static int pt_bind_accum_impl(pt_ctx *ctx, void *device_ptr)
 {
     PT_ENTER(ctx);
     if (ctx->window_size && device_ptr) return fail(ctx, PT_ERR_STATE, "pt_bind_accum: not available while a window is set (pt_set_window)");
@@ -1025,7 +1060,7 @@ int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
     return PT_OK;
 }
 
-int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
+static int pt_trace_rays_impl(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
 {
     PT_ENTER(ctx);
     if (n == 0) return PT_OK;
@@ -1068,4 +1103,216 @@ int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t
     return PT_OK;
 }
 
+
+// Nothing may propagate out of an extern "C" function: a C or Rust caller cannot catch it.
+int pt_create(int device, uint32_t width, uint32_t height, pt_ctx **out)
+{
+    try {
+        return pt_create_impl(device, width, height, out);
+    } catch (const std::bad_alloc &) {
+        return fail_static(nullptr, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(nullptr, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_stream(pt_ctx *ctx, void *hip_stream)
+{
+    try {
+        return pt_set_stream_impl(ctx, hip_stream);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_flags(pt_ctx *ctx, uint32_t flags)
+{
+    try {
+        return pt_set_flags_impl(ctx, flags);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_mesh(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
+{
+    try {
+        return pt_set_mesh_impl(ctx, tris_v, n_tris, nodes_v, n_nodes, tri_idx, n_idx);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_sky_cube(pt_ctx *ctx, const float *rgba32f, uint32_t size)
+{
+    try {
+        return pt_set_sky_cube_impl(ctx, rgba32f, size);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_sky_equirect(pt_ctx *ctx, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size)
+{
+    try {
+        return pt_set_sky_equirect_impl(ctx, rgba32f, w, h, cube_size);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_sky_cube(pt_ctx *ctx, float *out, size_t capacity_floats, uint32_t *size)
+{
+    try {
+        return pt_read_sky_cube_impl(ctx, out, capacity_floats, size);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_camera(pt_ctx *ctx, const void *camera64)
+{
+    try {
+        return pt_set_camera_impl(ctx, camera64);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_spheres(pt_ctx *ctx, const void *sphere_data8208)
+{
+    try {
+        return pt_set_spheres_impl(ctx, sphere_data8208);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_settings(pt_ctx *ctx, const void *settings16)
+{
+    try {
+        return pt_set_settings_impl(ctx, settings16);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_reset(pt_ctx *ctx)
+{
+    try {
+        return pt_reset_impl(ctx);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_sync(pt_ctx *ctx)
+{
+    try {
+        return pt_sync_impl(ctx);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_sum_rgba32f(pt_ctx *ctx, float *out)
+{
+    try {
+        return pt_read_sum_rgba32f_impl(ctx, out);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_mean_rgba32f(pt_ctx *ctx, float *out)
+{
+    try {
+        return pt_read_mean_rgba32f_impl(ctx, out);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_rgba8(pt_ctx *ctx, uint8_t *out)
+{
+    try {
+        return pt_read_rgba8_impl(ctx, out);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_set_window(pt_ctx *ctx, uint32_t sample_size)
+{
+    try {
+        return pt_set_window_impl(ctx, sample_size);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown)
+{
+    try {
+        return pt_read_window_impl(ctx, rgba32f_out, rgba8_out, frames_shown);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
+{
+    try {
+        return pt_read_aov_impl(ctx, prim, t);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_stats(pt_ctx *ctx, pt_stats_t *out)
+{
+    try {
+        return pt_stats_impl(ctx, out);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
+{
+    try {
+        return pt_bind_accum_impl(ctx, device_ptr);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
+{
+    try {
+        return pt_trace_rays_impl(ctx, origins, dirs, n, prim, t, p, normal, front);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
 }  // extern "C"

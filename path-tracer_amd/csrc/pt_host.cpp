@@ -21,6 +21,14 @@ namespace {
 
 thread_local std::string g_host_error;
 
+// for the catch-all guards: a message short enough for the string's in-place buffer, so that reporting an
+// allocation failure does not allocate
+int host_fail_static(int code, const char *msg) noexcept
+{
+    try { g_host_error.assign(msg); } catch (...) {}
+    return code;
+}
+
 int host_fail(int code, const std::string &msg)
 {
     g_host_error = msg;
@@ -284,10 +292,10 @@ bool parse_index(const char *&s, int count, int &out)
     const long raw = std::strtol(s, &end, 10);
     if (end == s) return false;
     s = end;
-    if (raw > 0) out = (int)(raw - 1);
-    else if (raw < 0) out = count + (int)raw;
-    else return false;
-    return out >= 0 && out < count;
+    // range-checked as a long: a narrowing cast first would let 4294967297 wrap to a valid index
+    if (raw == 0 || raw > (long)count || raw < -(long)count) return false;
+    out = raw > 0 ? (int)(raw - 1) : count + (int)raw;
+    return true;
 }
 
 // ---- Radiance .hdr (RGBE) decoding ------------------------------------------------------
@@ -411,7 +419,7 @@ extern "C" {
 
 const char *pt_host_error(void) { return g_host_error.c_str(); }
 
-int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
+static int64_t pt_bvh_build_impl(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
 {
     if (n_tris == 0) return 0;  // Bvh::from_triangles returns empty vectors, bvh.rs:35-41
     if (!tris || !nodes_out || !idx_out) return host_fail(PT_ERR_INVALID, "pt_bvh_build: null pointer");
@@ -431,7 +439,7 @@ int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_
     return (int64_t)used;
 }
 
-int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3], uint32_t material,
+static int pt_plane_triangles_impl(const float q[3], const float u[3], const float v[3], const float albedo[3], uint32_t material,
                        void *tris_out)
 {
     if (!q || !u || !v || !albedo || !tris_out) return host_fail(PT_ERR_INVALID, "pt_plane_triangles: null pointer");
@@ -461,7 +469,7 @@ int pt_plane_triangles(const float q[3], const float u[3], const float v[3], con
     return PT_OK;
 }
 
-int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data_out)
+static int pt_pack_spheres_impl(const float *spheres8, uint32_t n, void *sphere_data_out)
 {
     if ((!spheres8 && n) || !sphere_data_out) return host_fail(PT_ERR_INVALID, "pt_pack_spheres: null pointer");
     PtSphereData *out = static_cast<PtSphereData *>(sphere_data_out);
@@ -472,7 +480,7 @@ int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data_out)
     return PT_OK;
 }
 
-int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris)
+static int pt_obj_load_impl(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris)
 {
     if (!path || !n_tris) return host_fail(PT_ERR_INVALID, "pt_obj_load: null pointer");
     FILE *fp = std::fopen(path, "rb");
@@ -562,7 +570,7 @@ int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n
     return PT_OK;
 }
 
-int pt_hdr_decode(const void *data, size_t n_bytes, float *rgba_out, size_t capacity_pixels, uint32_t *width, uint32_t *height)
+static int pt_hdr_decode_impl(const void *data, size_t n_bytes, float *rgba_out, size_t capacity_pixels, uint32_t *width, uint32_t *height)
 {
     if (!data || !width || !height) return host_fail(PT_ERR_INVALID, "pt_hdr_decode: null pointer");
     HdrReader r{static_cast<const uint8_t *>(data), n_bytes, 0};
@@ -617,4 +625,57 @@ int pt_hdr_decode(const void *data, size_t n_bytes, float *rgba_out, size_t capa
     return PT_OK;
 }
 
+
+// Nothing may propagate out of an extern "C" function: a C or Rust caller cannot catch it.
+int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
+{
+    try {
+        return pt_bvh_build_impl(tris, n_tris, nodes_out, idx_out);
+    } catch (const std::bad_alloc &) {
+        return host_fail_static(PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return host_fail_static(PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3], uint32_t material,
+                       void *tris_out)
+{
+    try {
+        return pt_plane_triangles_impl(q, u, v, albedo, material, tris_out);
+    } catch (const std::bad_alloc &) {
+        return host_fail_static(PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return host_fail_static(PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_pack_spheres(const float *spheres8, uint32_t n, void *sphere_data_out)
+{
+    try {
+        return pt_pack_spheres_impl(spheres8, n, sphere_data_out);
+    } catch (const std::bad_alloc &) {
+        return host_fail_static(PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return host_fail_static(PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_obj_load(const char *path, void *tris_out, uint32_t capacity, uint32_t *n_tris)
+{
+    try {
+        return pt_obj_load_impl(path, tris_out, capacity, n_tris);
+    } catch (const std::bad_alloc &) {
+        return host_fail_static(PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return host_fail_static(PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_hdr_decode(const void *data, size_t n_bytes, float *rgba_out, size_t capacity_pixels, uint32_t *width, uint32_t *height)
+{
+    try {
+        return pt_hdr_decode_impl(data, n_bytes, rgba_out, capacity_pixels, width, height);
+    } catch (const std::bad_alloc &) {
+        return host_fail_static(PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return host_fail_static(PT_ERR_INTERNAL, "internal error");
+    }
+}
 }  // extern "C"

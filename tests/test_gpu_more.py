@@ -142,7 +142,7 @@ def test_equirect_to_cube_matches_oracle(pt, po, scenes):
     scene = scenes.three_balls()
     r = pt.Renderer(scene, 32, 20, settings=pt.Settings(1, 4, 1e-4, 1000.0))
     r.set_sky_equirect(pano, 64)
-    got = r.read_sky_cube(64)
+    got = r.read_sky_cube()
     want = po.equirect_to_cube(pano, 64)
     _exact(got, want, "cube texels")
     # and the renderer uses it
@@ -166,7 +166,7 @@ def test_hdr_file_to_sky_cube_matches_oracle(pt, po, scenes):
     assert np.abs(decoded[..., :3] - pano).max() <= pano.max() / 128.0
     r = pt.Renderer(scenes.three_balls(), 32, 20, settings=pt.Settings(1, 4, 1e-4, 1000.0))
     r.set_sky_equirect(decoded, 32)
-    _exact(r.read_sky_cube(32), po.equirect_to_cube(want_pano, 32), "cube texels from the .hdr")
+    _exact(r.read_sky_cube(), po.equirect_to_cube(want_pano, 32), "cube texels from the .hdr")
     r.close()
 
 

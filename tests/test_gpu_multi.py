@@ -1,0 +1,45 @@
+"""The sample split with the HIP renderer on every rank: two fresh worker processes share GPU 0, each renders its
+share f = g (mod 2) of 8 frames (frames are independent given their time value, compute.wgsl:85), the images are
+summed through gloo on host copies, and the result must be the one-process HIP image up to fp32 summation order,
+with the oracle's ray count."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import multi_worker
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_hip_ranks_sum_to_the_single_rank_image(pt, po, scenes, tmp_path, megakernel):
+    scene, sky, st, w, h, time0, frames = multi_worker.job(pt, scenes)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npz")
+    env = dict(os.environ, PTRT_KERNEL=megakernel or "")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_worker.py"), "--renderer", "hip", "--out", out,
+                               "--rank", str(g), "--world", "2", "--port", str(port)], env=env) for g in range(2)]
+    codes = [p.wait(timeout=110) for p in procs]
+    assert codes == [0, 0]
+    got = np.load(out)
+    # one process, the same frames frame after frame
+    r = pt.Renderer(scene, w, h, settings=st)
+    r.set_sky_cube(sky)
+    r.render_frames(time0, 1, frames)
+    one, rays = r.read_sum(), r.stats()["rays"]
+    r.close()
+    assert (got["sum"][..., 3] == frames).all() and int(got["rays"]) == rays
+    np.testing.assert_allclose(got["sum"], one, rtol=frames * 2.0 ** -23, atol=1e-6)
+    osc = po.from_scene(scene, w, h, st, sky)
+    want, orays = np.zeros((h, w, 4), np.float32), 0
+    for f in range(frames):
+        _, _, _, s = osc.render(time0 + f, want)
+        orays += s["rays"]
+    assert rays == orays
+    np.testing.assert_allclose(got["sum"], want, rtol=frames * 2.0 ** -23, atol=1e-6)

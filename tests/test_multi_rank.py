@@ -66,3 +66,51 @@ def test_two_rank_sum_equals_single_rank(pt, po, scenes, tmp_path):
         osc.render(5 + f, want, threads=2)
     assert (got[..., 3] == n_frames).all()
     np.testing.assert_allclose(got, want, rtol=n_frames * 2.0 ** -23, atol=1e-6)   # summation order only
+
+
+def test_bench_self_launch_starts_the_ranks(pt, po, scenes, tmp_path):
+    """`python bench.py --gpus N` without a torch.distributed environment starts N ranks through
+    torch.distributed.run on 127.0.0.1.  The same launch line, pointed at the CPU worker instead of bench.py, must
+    bring up two ranks that find each other through the environment and produce the single-rank image."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multi_worker
+    args = bench.parse_args(["--gpus", "2", "--steps", "3"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = bench.self_launch_command(args, ["--gpus", "2", "--steps", "3"], port)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    out = str(tmp_path / "sum.npz")
+    worker = cmd[:script] + [os.path.join(ROOT, "tests", "multi_worker.py"), "--renderer", "oracle", "--out", out]
+    assert subprocess.run(worker, timeout=170).returncode == 0
+    got = np.load(out)
+    scene, sky, st, w, h, time0, frames = multi_worker.job(pt, scenes)
+    osc = po.from_scene(scene, w, h, st, sky)
+    want, rays = np.zeros((h, w, 4), np.float32), 0
+    for f in range(frames):
+        _, _, _, s = osc.render(time0 + f, want, threads=2)
+        rays += s["rays"]
+    assert int(got["rays"]) == rays and (got["sum"][..., 3] == frames).all()
+    np.testing.assert_allclose(got["sum"], want, rtol=frames * 2.0 ** -23, atol=1e-6)
+
+
+def test_bench_frame_dealing(pt):
+    """Weak scaling gives every rank the configuration's frame count, strong scaling deals it; steps never share a time value."""
+    sys.path.insert(0, ROOT)
+    import bench
+    multi = importlib.import_module("path_tracer_amd.multi")
+    for scaling, per_rank in (("weak", 256), ("strong", 64)):
+        seen = set()
+        for step in range(3):
+            for g in range(4):
+                t0, stride, cnt = bench.frames_of_step(multi, g, 4, scaling, 256, step)
+                assert cnt == per_rank
+                times = {t0 + i * stride for i in range(cnt)}
+                assert not (times & seen)
+                seen |= times
+        assert len(seen) == 3 * 4 * per_rank
