@@ -1,0 +1,58 @@
+"""The Rust binding under bindings/rust cannot be compiled in this environment (no Rust toolchain), so its extern
+block is checked as text against include/ptrt.h: the same functions, in the same order, each with the same number
+of parameters and a matching return type; build.rs must pass the Makefile's numerical-contract flags."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _c_functions():
+    text = open(os.path.join(ROOT, "include", "ptrt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = text[text.index("typedef struct pt_stats_t"):]
+    out = []
+    for m in re.finditer(r"^(const char \*|void \*|void|int64_t|int)\s*(pt_\w+)\(([^;]*?)\);", text, flags=re.M | re.S):
+        params = m.group(3).strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        out.append((m.group(2), n, m.group(1).strip()))
+    return out
+
+
+def _rust_functions():
+    text = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    out = []
+    for m in re.finditer(r"pub fn (pt_\w+)\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        params = m.group(2).strip()
+        n = 0 if not params else len([p for p in params.split(",") if p.strip()])
+        out.append((m.group(1), n, (m.group(3) or "()").strip()))
+    return out
+
+
+def test_extern_block_matches_header():
+    c, rust = _c_functions(), _rust_functions()
+    assert len(c) >= 33
+    assert [f[0] for f in rust] == [f[0] for f in c]
+    ret = {"int": "i32", "int64_t": "i64", "void": "()", "const char *": "*const c_char", "void *": "*mut c_void"}
+    for (name, n, r), (_, rn, rr) in zip(c, rust):
+        assert n == rn, f"{name}: {n} parameters in ptrt.h, {rn} in lib.rs"
+        assert ret[r] == rr, f"{name}: returns {r} in ptrt.h, {rr} in lib.rs"
+
+
+def test_python_binding_lists_the_same_functions(pt):
+    assert [n for n, _, _ in pt.ABI] == [f[0] for f in _c_functions()]
+    for (name, _, args), (_, n, _) in zip(pt.ABI, _c_functions()):
+        assert len(args) == n, name
+
+
+def test_build_rs_carries_the_contract_flags():
+    rs = open(os.path.join(ROOT, "bindings", "rust", "build.rs")).read()
+    mk = open(os.path.join(ROOT, "path-tracer_amd", "csrc", "Makefile")).read()
+    for flag in ("--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                 "-fno-gpu-flush-denormals-to-zero", "-DPT_TRACE_WAVES_PER_EU=5"):
+        assert f'"{flag}"' in rs, flag
+    assert "--offload-arch=$(ARCH)" in mk and "-ffp-contract=off" in mk
+    for src in ("pt_api.hip", "pt_kernels.hip", "pt_host.cpp"):
+        assert src in rs and src in mk
