@@ -133,7 +133,7 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     const v3 o = ray.o, d = ray.d;
     // hitSphere, compute.wgsl:304-350
     const float a = dot3(d, d);
-    const float inv_den = 1.0f / (2.0f * a);
+    const float inv_den = pt_rcp(2.0f * a);
     const float a4 = 4.0f * a;
     for (uint32_t i = 0; i < sc.n_spheres; i++) {
         const float4 s0 = sc.spheres[3 * i];
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
         }
     }
     w.rec = rec;
-    w.inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    w.inv = pt_rcp3(d);
     w.nearest = 9999.0f;
     w.node = sc.root_token;
     w.sp = 0;
@@ -232,7 +232,7 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
         const v3 h = cross3(d, e2);
         const float a = dot3(e1, h);
         if (a > -0.00001f && a < 0.00001f) continue;
-        const float f = 1.0f / a;
+        const float f = pt_rcp(a);
         const v3 s = o - f4_xyz(A4);
         const float u = f * dot3(s, h);
         if (u < 0.0f || u > 1.0f) continue;
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
             const v3 h = cross3(d, e2);
             const float a = dot3(e1, h);
-            const float f = 1.0f / a;
+            const float f = pt_rcp(a);
             const v3 s = o - f4_xyz(q0);
             const float u = f * dot3(s, h);
             const v3 q = cross3(s, e1);
@@ -438,13 +438,13 @@ __device__ __forceinline__ v3 sky_lookup(const PtDeviceScene &sc, v3 d)
         face = d.x < 0.0f ? 1u : 0u; scoord = d.x < 0.0f ? d.z : -d.z; tcoord = -d.y; ma = ax;
     }
     const float size = (float)sc.sky_size;
-    const float inv_ma = 1.0f / ma;
+    const float inv_ma = pt_rcp(ma);
     const float fs = pt_fma(0.5f, scoord * inv_ma, 0.5f) * size;
     const float ft = pt_fma(0.5f, tcoord * inv_ma, 0.5f) * size;
     const uint32_t hi = sc.sky_size - 1u;
     const uint32_t i = (fs >= 0.0f) ? (fs < size ? (uint32_t)fs : hi) : 0u;
     const uint32_t j = (ft >= 0.0f) ? (ft < size ? (uint32_t)ft : hi) : 0u;
-    const float4 tx = sc.sky[((size_t)face * sc.sky_size + j) * sc.sky_size + i];
+    const float4 tx = sc.sky[(face * sc.sky_size + j) * sc.sky_size + i];  // at most 6 * 16384^2 texels: 32-bit arithmetic
     return V3(tx.x, tx.y, tx.z);
 }
 
@@ -568,6 +568,14 @@ __device__ __forceinline__ void pt_mark_global(T *&p)
     typedef __attribute__((address_space(1))) T *G;
     p = (T *)(G)(uintptr_t)p;
 }
+// Read-only for the whole launch and indexed wave-uniformly (the sphere records): constant address space, so that
+// the loads are scalar loads again and do not make the pass wait for its outstanding vector loads.
+template <typename T>
+__device__ __forceinline__ void pt_mark_constant(T *&p)
+{
+    typedef __attribute__((address_space(4))) T *G;
+    p = (T *)(G)(uintptr_t)p;
+}
 __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 {
     PtKernargWords kw = (PtKernargWords)__builtin_amdgcn_kernarg_segment_ptr();  // the block is the kernel's only argument
@@ -575,7 +583,7 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
     uint32_t *lw = reinterpret_cast<uint32_t *>(&L);
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
-    pt_mark_global(L.sc.spheres); pt_mark_global(L.sc.nodes); pt_mark_global(L.sc.node_meta);
+    pt_mark_constant(L.sc.spheres); pt_mark_global(L.sc.nodes); pt_mark_global(L.sc.node_meta);
     pt_mark_global(L.sc.tri_pos); pt_mark_global(L.sc.tri_nrm); pt_mark_global(L.sc.sky);
     pt_mark_global(L.items); pt_mark_global(L.partial); pt_mark_global(L.cost); pt_mark_global(L.accum);
     pt_mark_global(L.aov_prim); pt_mark_global(L.aov_t); pt_mark_global(L.counters); pt_mark_global(L.gstack);
@@ -901,6 +909,7 @@ struct PPFields {
 };
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
+enum : uint32_t { R_MISS = 0, R_HIT = 1, R_PEND = 2 };
 // Ring entries are slot id + 1 in 16 bits.
 typedef uint16_t pp_entry;
 __device__ __forceinline__ uint32_t ring_load(pp_entry *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -910,10 +919,10 @@ template <uint32_t NF, uint32_t PATHS>
 struct PPShared {
     uint32_t st[NF][PATHS];
     uint32_t stack[PT_PP_STACK][PT_PP_THREADS];
-    pp_entry ready[PT_PP_QCAP];     // READY, ray missed everything (or no ray yet): sky, next path
-    pp_entry ready_hit[PT_PP_QCAP]; // READY, ray hit something: material, bounce
-    pp_entry pending[PT_PP_QCAP];
-    uint32_t ready_head, ready_tail, hit_head, hit_tail, pend_head, pend_tail;
+    // rings: R_MISS = READY, ray missed everything (or no ray yet): sky, next path; R_HIT = READY, ray hit
+    // something: material, bounce; R_PEND = PENDING, ray needs a walk
+    pp_entry ring[3][PT_PP_QCAP];
+    uint32_t head[3], tail[3];
     uint32_t busy[PT_PP_WAVES];  // walkers per wave, published every trip
     uint32_t live;               // slots that still have, or may still get, a job
     // the group's open work item: its pixels are handed out in order to slots that need a job
@@ -991,24 +1000,26 @@ __device__ __forceinline__ void ring_push(pp_entry *ring, uint32_t *tail, bool m
 }
 
 // Three pushes at once (a lane appends to at most one of the rings): one fence, and the three tail
-// reservations made by three lanes in the same instruction instead of one after the other.
-__device__ __forceinline__ void ring_push3(pp_entry *r0, uint32_t *t0, bool m0, pp_entry *r1, uint32_t *t1, bool m1, pp_entry *r2, uint32_t *t2,
-                                           bool m2, uint32_t id, uint32_t lane, unsigned long long lt_mask)
+// reservations made by lanes 0..2 in the same instruction instead of one after the other.  `tails` and `rings`
+// are the three rings' tail words and entry arrays, in ring order.
+__device__ __forceinline__ void ring_push3(pp_entry (*rings)[PT_PP_QCAP], uint32_t *tails, bool m0, bool m1, bool m2, uint32_t id, uint32_t lane,
+                                           unsigned long long lt_mask)
 {
     const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1), b2 = __ballot(m2);
     if ((b0 | b1 | b2) == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the slots' state is written before their ids show up
     uint32_t base = 0;
     {
-        const uint32_t n = lane == 0 ? (uint32_t)__popcll(b0) : lane == 1 ? (uint32_t)__popcll(b1) : (uint32_t)__popcll(b2);
-        uint32_t *t = lane == 0 ? t0 : lane == 1 ? t1 : t2;
-        if (lane < 3u && n != 0u) base = atomicAdd(t, n);
+        uint32_t l = lane;
+        asm volatile("" : "+v"(l));  // (otherwise "lane < 3" is computed once and sits in a scalar register pair for the whole kernel)
+        const uint32_t n = l == 0 ? (uint32_t)__popcll(b0) : l == 1 ? (uint32_t)__popcll(b1) : (uint32_t)__popcll(b2);
+        if (l < 3u && n != 0u) base = atomicAdd(&tails[l], n);
     }
     const uint32_t base0 = __shfl(base, 0, 64), base1 = __shfl(base, 1, 64), base2 = __shfl(base, 2, 64);
     if (m0 || m1 || m2) {
-        pp_entry *ring = m0 ? r0 : m1 ? r1 : r2;
+        const uint32_t k = m0 ? 0u : m1 ? 1u : 2u;
         const uint32_t pos = m0 ? base0 + (uint32_t)__popcll(b0 & lt_mask) : m1 ? base1 + (uint32_t)__popcll(b1 & lt_mask) : base2 + (uint32_t)__popcll(b2 & lt_mask);
-        pp_entry *e = &ring[pos & (PT_PP_QCAP - 1u)];
+        pp_entry *e = &rings[k][pos & (PT_PP_QCAP - 1u)];
         ring_wait_empty(e);
         ring_store(e, id + 1u);
     }
@@ -1063,9 +1074,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's index, as a scalar: comparisons with it need no lane masks
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const PtDeviceScene &sc = P.sc;
-    for (uint32_t i = tid; i < PT_PP_QCAP; i += PT_PP_THREADS) { sh.ready[i] = 0; sh.ready_hit[i] = 0; sh.pending[i] = 0; }
+    for (uint32_t i = tid; i < PT_PP_QCAP; i += PT_PP_THREADS) { sh.ring[R_MISS][i] = 0; sh.ring[R_HIT][i] = 0; sh.ring[R_PEND][i] = 0; }
     if (tid == 0) {
-        sh.ready_head = sh.ready_tail = sh.hit_head = sh.hit_tail = sh.pend_head = sh.pend_tail = 0;
+        for (uint32_t i = 0; i < 3; i++) sh.head[i] = sh.tail[i] = 0;
         for (uint32_t i = 0; i < PT_PP_WAVES; i++) sh.busy[i] = 0;
         sh.live = FL::PATHS;
         sh.job_word = 64u;
@@ -1161,7 +1172,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         const bool need = base + lane < FL::SEED;
         const uint32_t p = wv * FL::SEED + base + lane;
         const bool got = assign_jobs(need, p);
-        ring_push(sh.ready, &sh.ready_tail, got, p, lane, lt_mask);
+        ring_push(sh.ring[R_MISS], &sh.tail[R_MISS], got, p, lane, lt_mask);
         const uint32_t n_dead = (uint32_t)__popcll(__ballot(need && !got));
         if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
     }
@@ -1200,11 +1211,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         dg_trips++;
 #endif
         // wave-uniform view of the pool
-        uint32_t n_pend = lds_load_uniform(&sh.pend_tail) - lds_load_uniform(&sh.pend_head);
+        uint32_t n_pend = lds_load_uniform(&sh.tail[R_PEND]) - lds_load_uniform(&sh.head[R_PEND]);
         if (n_pend > PT_PP_QCAP) n_pend = 0;
-        uint32_t n_miss = lds_load_uniform(&sh.ready_tail) - lds_load_uniform(&sh.ready_head);
+        uint32_t n_miss = lds_load_uniform(&sh.tail[R_MISS]) - lds_load_uniform(&sh.head[R_MISS]);
         if (n_miss > PT_PP_QCAP) n_miss = 0;
-        uint32_t n_hit = lds_load_uniform(&sh.hit_tail) - lds_load_uniform(&sh.hit_head);
+        uint32_t n_hit = lds_load_uniform(&sh.tail[R_HIT]) - lds_load_uniform(&sh.head[R_HIT]);
         if (n_hit > PT_PP_QCAP) n_hit = 0;
         const unsigned long long free_mask = __ballot(!wbusy);
         const uint32_t n_free = (uint32_t)__popcll(free_mask);
@@ -1227,7 +1238,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         const bool leader = best_other < (int32_t)((64u - n_free) * PT_PP_WAVES + (PT_PP_WAVES - 1u - wv));
         if (n_pend != 0u && n_free != 0u &&
             (desperate || (leader ? (n_free >= PT_TUNE(P.pool_topup, PT_POOL_TOPUP) || n_pend >= n_free || n_free == 64u) : n_pend >= PT_TUNE(P.pool_start, PT_POOL_START) + 64u))) {
-            const uint32_t id = ring_pop(sh.pending, &sh.pend_head, &sh.pend_tail, free_mask, lane, lt_mask, FL::PATHS);
+            const uint32_t id = ring_pop(sh.ring[R_PEND], &sh.head[R_PEND], &sh.tail[R_PEND], free_mask, lane, lt_mask, FL::PATHS);
             if (id != 0xFFFFFFFFu) {
                 const uint32_t p = id;
                 wpath = p;
@@ -1239,7 +1250,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 w.rec.index = hid & 0x3FFFFFFFu;
                 w.rec.t = __uint_as_float(sh.st[F_T][p]);
                 w.rec.u = w.rec.v = 0.0f;
-                w.inv = V3(1.0f / wray.d.x, 1.0f / wray.d.y, 1.0f / wray.d.z);
+                w.inv = pt_rcp3(wray.d);
                 w.nearest = 9999.0f;
                 w.node = sh.st[F_U][p];
                 w.sp = 0;
@@ -1295,12 +1306,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 if (__ballot(wbusy) == 0ull || k + 1u >= PT_TUNE(P.pool_steps, PT_POOL_STEPS)) break;
             }
             __builtin_amdgcn_s_setprio(0);
-            ring_push3(sh.ready, &sh.ready_tail, fin && !w.rec.hit, sh.ready_hit, &sh.hit_tail, fin && w.rec.hit, sh.pending, &sh.pend_tail, false, wpath, lane,
-                       lt_mask);
+            ring_push3(sh.ring, sh.tail, fin && !w.rec.hit, fin && w.rec.hit, false, wpath, lane, lt_mask);
             if (__ballot(fin)) {
-                n_miss = lds_load_uniform(&sh.ready_tail) - lds_load_uniform(&sh.ready_head);
+                n_miss = lds_load_uniform(&sh.tail[R_MISS]) - lds_load_uniform(&sh.head[R_MISS]);
                 if (n_miss > PT_PP_QCAP) n_miss = 0;
-                n_hit = lds_load_uniform(&sh.hit_tail) - lds_load_uniform(&sh.hit_head);
+                n_hit = lds_load_uniform(&sh.tail[R_HIT]) - lds_load_uniform(&sh.head[R_HIT]);
                 if (n_hit > PT_PP_QCAP) n_hit = 0;
             }
         }
@@ -1337,8 +1347,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             // texel of a miss) are issued first, and the next ray is set up before their values are used.
             auto shading_pass = [&](auto hits_tag) {
                 constexpr bool HITS = decltype(hits_tag)::value;
-                p = HITS ? ring_pop(sh.ready_hit, &sh.hit_head, &sh.hit_tail, ~0ull, lane, lt_mask, FL::PATHS)
-                         : ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask, FL::PATHS);
+                p = HITS ? ring_pop(sh.ring[R_HIT], &sh.head[R_HIT], &sh.tail[R_HIT], ~0ull, lane, lt_mask, FL::PATHS)
+                         : ring_pop(sh.ring[R_MISS], &sh.head[R_MISS], &sh.tail[R_MISS], ~0ull, lane, lt_mask, FL::PATHS);
 #ifdef PT_DIAG
                 if (!HITS) { const unsigned long long t = clock64(); dg_sec[0] += t - dg_s; dg_s2 = t; }
 #endif
@@ -1526,7 +1536,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             // needs a walk (state to LDS, slot to the matching ring) or when their job ends, and the loop ends
             // when too few lanes are left or after pool_miss_iters rounds.
             auto miss_pass = [&]() {
-                p = ring_pop(sh.ready, &sh.ready_head, &sh.ready_tail, ~0ull, lane, lt_mask, FL::PATHS);
+                p = ring_pop(sh.ring[R_MISS], &sh.head[R_MISS], &sh.tail[R_MISS], ~0ull, lane, lt_mask, FL::PATHS);
                 bool mine = p != 0xFFFFFFFFu;  // this lane still carries its slot through the loop
                 uint32_t x = 0, y = 0, frame_end = 0, pidx = 0, frame = 0, sample = 0, cost = 0;
                 bool have_ray = false, want_aov = false, dirty = false;
@@ -1699,7 +1709,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t n_dead = (uint32_t)__popcll(__ballot(finished && !got));
                 if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
             }
-            ring_push3(sh.pending, &sh.pend_tail, to_pending, sh.ready, &sh.ready_tail, to_ready, sh.ready_hit, &sh.hit_tail, to_hit, p, lane, lt_mask);
+            ring_push3(sh.ring, sh.tail, to_ready, to_hit, to_pending, p, lane, lt_mask);
             const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
             if (gotm) did_work = true;
 #ifdef PT_DIAG
