@@ -34,6 +34,7 @@ fn main() {
             "-fhip-fp32-correctly-rounded-divide-sqrt",
             "-fno-gpu-flush-denormals-to-zero",
             "-mfma",
+            "-fno-slp-vectorize",
         ])
         .args(sources.iter().map(|f| src.join(f)))
         .arg("-o")

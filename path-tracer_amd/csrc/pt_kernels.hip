@@ -598,7 +598,8 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 // SPP1: one sample per pixel and dispatch (the per-frame sample sum is the sample itself);
 // DIRECT: no item table -- work item i is tile i with every frame, added straight onto the sums.
 template <bool STATS, bool OVERFLOW, bool GIZMO, bool SPP1, bool DIRECT>
-__global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_WAVES_PER_EU) void trace_kernel(const PtTraceParams P)
+// (the variant that keeps nine counters per lane gets the registers of four waves per SIMD instead of five)
+__global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 ? PT_TRACE_WAVES_PER_EU : 4) : PT_TRACE_WAVES_PER_EU) void trace_kernel(const PtTraceParams P)
 {
     // one wave per workgroup = one 8x8 pixel tile; lane -> (l&7, l>>3).  Single-wave groups
     // retire independently, so a slow wave never pins the LDS and wave slots of finished ones.
