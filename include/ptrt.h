@@ -125,8 +125,8 @@ int pt_render(pt_ctx *ctx, uint32_t time);
 int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames);
 /* Device memory pt_render_frames allocates on demand and keeps until pt_destroy (it never shrinks): the work-item
  * table and partial sums of the largest launch so far, 1040 bytes per planned work item -- launches of 16 frames
- * or more plan tiles + 5120*k + 1024 items, k = frames/6 clamped to 6..64 for the pooled kernel and 2 for the
- * per-tile one (1080p: 45 MB at 16 frames, 260 MB at 256); launches of 2..15 frames plan tiles*(frames+1) + 11264
+ * or more plan tiles + 5120*k + 1024 items, k = frames/4 clamped to 6..64 for the pooled kernel and 2 for the
+ * per-tile one (1080p: 45 MB at 16 frames, 375 MB at 256); launches of 2..15 frames plan tiles*(frames+1) + 11264
  * items as long as that stays below 640 MiB (1080p, 15 frames: 551 MB) and otherwise run frame after frame with no
  * such memory -- and, for BVHs deeper than the kernels' on-chip stacks (24 levels per-tile, 8 pooled), 4 bytes per
  * lane and extra level.  The first call that needs more than the context holds synchronises the stream, frees and
@@ -135,7 +135,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
  * graph capture, serving loops, harnesses that forbid hipMalloc): the same launches as pt_render_frames, bit for
  * bit, but the work-item table, the partial sums and the deep-stack spill space come from a static 192 MiB device
  * array that the library holds once per GPU for the life of the process, and no hipMalloc / hipFree is called.
- * A launch that needs more (see above; 1080p: up to about 128 frames per call) is rejected with PT_ERR_LIMIT and
+ * A launch that needs more (see above; 1080p: up to about 100 frames per call) is rejected with PT_ERR_LIMIT and
  * nothing is rendered: ask for fewer frames per call.  Not available while a window is set.  All contexts of a GPU
  * share the array: calls that overlap in time on one GPU (different streams or threads) race; calls that follow one
  * another on a stream, or are separated by pt_sync, do not.  A plan is re-used only by the context that wrote it. */

@@ -705,13 +705,15 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     sch.tile_items = ctx->tile_items;
     sch.cost_valid = &ctx->cost_valid;
     // Items per resident wave slot.  Pooled kernel: a pixel's frames run one after the other, so costly tiles need
-    // short items, but every item costs 64 job hand-outs and a row of partial sums: about one item per slot and six
-    // frames of the launch is best (bench scene: 22 at 128 frames, 33 at 192, 36-44 at 256, 64 at 512).  Per-tile
-    // kernel: every item costs a wave its start-up and its ragged end.
+    // short items, but every item costs 64 job hand-outs and a row of partial sums: one item per slot and four
+    // frames of the launch, at most 64 (bench scene, Grays/s: 64 frames 26.2 / 27.8 / 30.6 / 30.3 at 8 / 10 / 16 / 21;
+    // 128 frames 33.4 / 34.2 / 34.2 / 33.7 at 16 / 21 / 32 / 42; 256 frames 33.7 / 35.0 / 35.6 / 34.9 / 33.6 at
+    // 32 / 42 / 64 / 96 / 128; 512 frames 36.1 / 36.6 / 35.2 at 64 / 85 / 128).  Per-tile kernel: every item costs a
+    // wave its start-up and its ragged end.
     // A frame of several samples per pixel counts as that many frames here.
     const uint32_t spp = std::max(ctx->settings.samples_per_pixel, 1u);
     const uint32_t launch_samples = (uint32_t)std::min<uint64_t>((uint64_t)launch_frames * spp, 1u << 20);
-    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_samples / 6u, 6u), 64u) : 2);
+    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_samples / 4u, 6u), 64u) : 2);
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);

@@ -37,10 +37,10 @@
 #define PT_SHORT_LAUNCH_SCRATCH_LIMIT (640ull << 20)
 #define PT_PLAN_REUSE_PERIOD 8u  // pooled kernel, identical launches: of 8, six run the old plan, one also measures, one plans anew
 // pooled kernel: scheduling thresholds (see PtTraceParams for what each one means)
-#define PT_POOL_START 32u
+#define PT_POOL_START 0u
 #define PT_POOL_TOPUP 16u
 #define PT_POOL_DENSE 16u
-#define PT_POOL_SHADE_DENSE 48u
+#define PT_POOL_SHADE_DENSE 32u
 #define PT_POOL_REFILL_LANES 32u
 #define PT_POOL_STEPS 8u
 #define PT_POOL_MISS_ITERS 32u
