@@ -36,8 +36,9 @@ PT_HD float pt_abs(float a) { return __builtin_fabsf(a); }
 PT_HD float pt_rcp(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // (one wave-uniform branch: if any active lane needs the general sequence, all take it)
     const uint32_t ex = __float_as_uint(x) & 0x7F800000u;
-    if (__builtin_expect(ex - 0x00800000u < 0x7E000000u, 1)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(ex - 0x00800000u < 0x7E000000u)) == 0ull, 1)) {
         const float r = __builtin_amdgcn_rcpf(x);
         return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
     }
@@ -48,7 +49,7 @@ PT_HD float pt_rcp(float x)
 PT_HD float pt_sqrt(float a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_expect(__float_as_uint(a) - 0x0D800000u < 0x7F800000u - 0x0D800000u, 1)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__float_as_uint(a) - 0x0D800000u < 0x7F800000u - 0x0D800000u)) == 0ull, 1)) {
         const float s = __builtin_amdgcn_sqrtf(a);
         const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
         float r = __builtin_fmaf(-lo, s, a) <= 0.0f ? lo : s;
@@ -87,7 +88,7 @@ PT_HD v3 pt_rcp3(v3 d)
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t ex = __float_as_uint(d.x) & 0x7F800000u, ey = __float_as_uint(d.y) & 0x7F800000u, ez = __float_as_uint(d.z) & 0x7F800000u;
     const uint32_t lo = min(min(ex, ey), ez), hi = max(max(ex, ey), ez);
-    if (__builtin_expect(lo >= 0x00800000u && hi < 0x7E800000u, 1)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(lo >= 0x00800000u && hi < 0x7E800000u)) == 0ull, 1)) {
         const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
         return V3(__builtin_fmaf(__builtin_fmaf(-d.x, rx, 1.0f), rx, rx), __builtin_fmaf(__builtin_fmaf(-d.y, ry, 1.0f), ry, ry),
                   __builtin_fmaf(__builtin_fmaf(-d.z, rz, 1.0f), rz, rz));
