@@ -669,7 +669,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     else
         use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && samples_now >= PT_POOL_MIN_FRAMES &&
                     (launch_frames == 1u || launch_frames >= PT_POOL_MULTI_MIN_FRAMES)) ||
-                   (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES_LONG && samples_now >= PT_POOL_LONG_FRAMES &&
+                   (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES_LONG && samples_now >= PT_POOL_MULTI_LONG_SAMPLES &&
                     launch_frames >= PT_POOL_MULTI_MIN_FRAMES);
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;

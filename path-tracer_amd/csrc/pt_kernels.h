@@ -21,15 +21,19 @@
 #define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
 // At one sample per pixel and frame the pooled kernel takes launches on meshes of at least
 // PT_POOL_MIN_TRIANGLES of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
-// PT_POOL_MIN_TRIANGLES_LONG of at least PT_POOL_LONG_FRAMES frames.
+// PT_POOL_MIN_TRIANGLES_LONG of at least PT_POOL_LONG_FRAMES frames (pooled / per-tile, 1080p, depth 8: 96 frames
+// 0.99 at 192 triangles, 1.14 at 768, 1.02 at 3 k, 1.23 from 8.7 k on; 48 frames 1.02 at 768, 0.86 at 3 k, 1.12-1.24
+// from 8.7 k on; 32 frames 0.97-1.08 from 8.7 k on).
 #define PT_POOL_MIN_TRIANGLES 8192u
 #define PT_POOL_MIN_FRAMES 48u
 #define PT_POOL_MIN_TRIANGLES_LONG 512u
-#define PT_POOL_LONG_FRAMES 192u
+#define PT_POOL_LONG_FRAMES 96u
 // With several samples per pixel and frame the same rule counts samples per launch instead of frames, for launches
-// of one frame or of at least PT_POOL_MULTI_MIN_FRAMES, and asks PT_POOL_MULTI_MIN_TRIANGLES_LONG of a long launch.
+// of one frame or of at least PT_POOL_MULTI_MIN_FRAMES, and asks PT_POOL_MULTI_MIN_TRIANGLES_LONG triangles and
+// PT_POOL_MULTI_LONG_SAMPLES samples of a long launch.
 #define PT_POOL_MULTI_MIN_FRAMES 16u
 #define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
+#define PT_POOL_MULTI_LONG_SAMPLES 192u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
 // Launches of 2..15 frames plan one work item (a 1 KiB row of partial sums) per tile and frame so that the frames
 // run side by side; above this many bytes of such rows they run frame after frame instead (one item per tile, no
