@@ -14,6 +14,7 @@
 //   tri_nrm   3 float4 per slot     vertex normals, touched once per closest hit
 //   sky       6*size*size float4    cube faces +X,-X,+Y,-Y,+Z,-Z
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -236,6 +237,54 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.t_min = ctx->settings.t_min;
     sc.t_max = ctx->settings.t_max;
     return sc;
+}
+
+// Screen rectangles of the root's two child boxes (PtTraceParams::cull).  A camera ray of pixel (px, py), jittered by
+// at most half a pixel, has the direction pixel00 + px du + py dv - origin (compute.wgsl:109-119); a point P of a box is
+// seen along (px, py) = (a / c, b / c) where (a, b, c) solves [du dv pixel00-origin] (a, b, c)^T = P - origin, c > 0.
+// The image of a convex box is the hull of its corners' images, so a pixel more than the jitter outside their
+// bounding rectangle sees nothing of the box; two pixels of margin cover the jitter and every rounding on the way
+// (double arithmetic here against the kernels' float slab test, whose error is some 1e-7 of the distances).  A box
+// with a corner at or behind the camera gets no statement.
+void camera_cull_rects(const pt_ctx *ctx, const pt_frame &fr, uint32_t cull[8])
+{
+    for (int k = 0; k < 2; k++) { cull[4 * k] = 0; cull[4 * k + 1] = 0xFFFFFFFFu; cull[4 * k + 2] = 0; cull[4 * k + 3] = 0xFFFFFFFFu; }
+    if (ctx->n_nodes == 0 || (ctx->root_token & PT_TOKEN_LEAF)) return;
+    const double m[3][3] = {{fr.du.x, fr.dv.x, (double)fr.pixel00.x - fr.origin.x},
+                            {fr.du.y, fr.dv.y, (double)fr.pixel00.y - fr.origin.y},
+                            {fr.du.z, fr.dv.z, (double)fr.pixel00.z - fr.origin.z}};
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return;
+    const float4 *q = ctx->root_pair;  // {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x} {lmax.y rmax.y lmax.z rmax.z}
+    for (int k = 0; k < 2; k++) {
+        const double lo[3] = {k ? q[0].y : q[0].x, k ? q[0].w : q[0].z, k ? q[1].y : q[1].x};
+        const double hi[3] = {k ? q[1].w : q[1].z, k ? q[2].y : q[2].x, k ? q[2].w : q[2].z};
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        bool ok = true;
+        for (int c = 0; c < 8 && ok; c++) {
+            const double v[3] = {((c & 1) ? hi[0] : lo[0]) - fr.origin.x, ((c & 2) ? hi[1] : lo[1]) - fr.origin.y, ((c & 4) ? hi[2] : lo[2]) - fr.origin.z};
+            // Cramer's rule
+            const double a = (v[0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (v[1] * m[2][2] - m[1][2] * v[2]) + m[0][2] * (v[1] * m[2][1] - m[1][1] * v[2])) / det;
+            const double b = (m[0][0] * (v[1] * m[2][2] - m[1][2] * v[2]) - v[0] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * v[2] - v[1] * m[2][0])) / det;
+            const double cc = (m[0][0] * (m[1][1] * v[2] - v[1] * m[2][1]) - m[0][1] * (m[1][0] * v[2] - v[1] * m[2][0]) + v[0] * (m[1][0] * m[2][1] - m[1][1] * m[2][0])) / det;
+            if (!(cc > 1e-6) || !std::isfinite(a) || !std::isfinite(b)) { ok = false; break; }  // at or behind the camera
+            const double px = a / cc, py = b / cc;
+            if (!std::isfinite(px) || !std::isfinite(py)) { ok = false; break; }
+            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+        if (!ok) continue;
+        const double margin = 2.0;
+        const double W = ctx->width, H = ctx->height;
+        const double ax0 = std::floor(x0 - margin), ax1 = std::ceil(x1 + margin), ay0 = std::floor(y0 - margin), ay1 = std::ceil(y1 + margin);
+        if (ax1 < 0.0 || ay1 < 0.0 || ax0 > W - 1.0 || ay0 > H - 1.0) {  // entirely off screen
+            cull[4 * k] = 0xFFFFFFFFu; cull[4 * k + 1] = 0; cull[4 * k + 2] = 0xFFFFFFFFu; cull[4 * k + 3] = 0;
+            continue;
+        }
+        const uint32_t ix0 = (uint32_t)std::max(ax0, 0.0), ix1 = (uint32_t)std::min(ax1, W - 1.0);
+        const uint32_t iy0 = (uint32_t)std::max(ay0, 0.0), iy1 = (uint32_t)std::min(ay1, H - 1.0);
+        cull[4 * k] = ix0; cull[4 * k + 1] = ix1 - ix0; cull[4 * k + 2] = iy0; cull[4 * k + 3] = iy1 - iy0;
+    }
 }
 
 int ensure_gstack(pt_ctx *ctx, size_t bytes)
@@ -624,6 +673,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     PtTraceParams p{};
     p.sc = device_scene(ctx);
     p.fr = pt_camera_frame(reinterpret_cast<const float *>(&ctx->camera), ctx->width, ctx->height);
+    camera_cull_rects(ctx, p.fr, p.cull);
     p.width = ctx->width;
     p.height = ctx->height;
     p.cols = ctx->width;

@@ -82,6 +82,11 @@ struct PtTraceParams {
     bool has_gizmo;          // a sphere with material 3 exists (selects the kernel variant)
     float inv_spp;           // 1 / spp, rounded once on the host
     uint32_t time0, stride, n_frames;
+    // Screen rectangles (in pixels, two pixels of margin) that contain everything a camera ray can see of the root's two
+    // child boxes: {x0, x1 - x0, y0, y1 - y0} per child.  A camera ray of a pixel outside both cannot enter either box, so
+    // its root visit is known to end the walk without being computed.  {0, 0xFFFFFFFF, 0, 0xFFFFFFFF}: no statement
+    // (box partly behind the camera, no BVH, root is a leaf); {0xFFFFFFFF, 0, 0xFFFFFFFF, 0}: box entirely off screen.
+    uint32_t cull[8];
     uint32_t refill_lanes;   // run the shading block once this many lanes of a wave wait for it
     uint32_t tiles_x, tiles_y, n_tiles;  // filled in by pt_launch_trace
     const uint4 *items;      // filled in by pt_launch_trace: {tile, first frame, frame count, 0} per work item

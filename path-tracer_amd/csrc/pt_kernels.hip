@@ -121,8 +121,18 @@ __device__ __forceinline__ void pt_fresh_root_pair(float4 &q0, float4 &q1, float
     k2 = kw[o + 13];
 }
 
+// Is pixel (x, y) outside both screen rectangles of PtTraceParams::cull (camera rays only)?
+__device__ __forceinline__ bool pt_camera_ray_misses_bvh(const uint32_t (&cull)[8], uint32_t x, uint32_t y)
+{
+    const bool out0 = (x - cull[0] > cull[1]) || (y - cull[2] > cull[3]);
+    const bool out1 = (x - cull[4] > cull[5]) || (y - cull[6] > cull[7]);
+    return out0 && out1;
+}
+
+// skip_root: the caller knows that this ray enters neither of the root's child boxes (a camera ray of a pixel outside
+// their screen rectangles): the root visit is counted but not computed.
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
+__device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root = false)
 {
     Closest rec;
     rec.hit = false;
@@ -166,11 +176,15 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
         }
     }
     w.rec = rec;
-    w.inv = pt_rcp3(d);
     w.nearest = 9999.0f;
     w.node = sc.root_token;
     w.sp = 0;
     if (sc.n_nodes == 0) return false;
+    if (skip_root) {  // (only ever set when the root is an interior node)
+        if (STATS) cn.interior++;
+        return false;
+    }
+    w.inv = pt_rcp3(d);
     if (sc.root_token & PT_TOKEN_LEAF) return true;
     // First visit (the root's two children) from wave-uniform registers instead of memory: most
     // rays of an outdoor scene end their walk right here.
@@ -180,9 +194,11 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     uint32_t k1, k2;
     pt_fresh_root_pair(r0, r1, r2, k1, k2);
     hit_aabb_pair(o, w.inv, r0, r1, r2, d1, d2);
-    if (d1 > d2) {
-        const float td = d1; d1 = d2; d2 = td;
-        const uint32_t tk = k1; k1 = k2; k2 = tk;
+    {  // near child first (selects: cheaper than a lane mask around four moves)
+        const bool far_first = d1 > d2;
+        const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
+        const uint32_t kn = far_first ? k2 : k1, kf = far_first ? k1 : k2;
+        d1 = n; d2 = f; k1 = kn; k2 = kf;
     }
     if (d1 > w.nearest) return false;  // stack is empty: walk over (compute.wgsl:263-265)
     w.node = k1;
@@ -203,9 +219,11 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
         float d1, d2;
         hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
         uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
-        if (d1 > d2) {
-            const float td = d1; d1 = d2; d2 = td;
-            const uint32_t tk = k1; k1 = k2; k2 = tk;
+        {  // near child first (selects: cheaper than a lane mask around four moves)
+            const bool far_first = d1 > d2;
+            const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
+            const uint32_t kn = far_first ? k2 : k1, kf = far_first ? k1 : k2;
+            d1 = n; d2 = f; k1 = kn; k2 = kf;
         }
         if (d1 > w.nearest) {
             if (w.sp == 0) return true;
@@ -301,9 +319,11 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             float d1, d2;
             hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
             uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
-            if (d1 > d2) {
-                const float td = d1; d1 = d2; d2 = td;
-                const uint32_t tk = k1; k1 = k2; k2 = tk;
+            {  // near child first (selects: cheaper than a lane mask around four moves)
+                const bool far_first = d1 > d2;
+                const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
+                const uint32_t kn = far_first ? k2 : k1, kf = far_first ? k1 : k2;
+                d1 = n; d2 = f; k1 = kn; k2 = kf;
             }
             if (d1 > w.nearest) {
                 next_node = true;
@@ -354,7 +374,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
 // walk_begin for the pooled kernel: same spheres + root visit, but the far child (if it has to be
 // visited) is returned in k2 instead of being pushed, because the walk may run on another lane.
 template <bool STATS>
-__device__ __forceinline__ bool walk_begin_pool(const PtDeviceScene &sc, const Ray &ray, Walk &w, uint32_t &k2_out, Counters &cn)
+__device__ __forceinline__ bool walk_begin_pool(const PtDeviceScene &sc, const Ray &ray, Walk &w, uint32_t &k2_out, Counters &cn, bool skip_root = false)
 {
     struct OneSlot {
         uint32_t v;
@@ -368,7 +388,7 @@ __device__ __forceinline__ bool walk_begin_pool(const PtDeviceScene &sc, const R
         __device__ __forceinline__ uint32_t pop(uint32_t sp) { return p->pop(sp); }
     };
     OneSlot slot{0xFFFFFFFFu, false};
-    const bool need = walk_begin<STATS>(sc, ray, w, Ref{&slot}, cn);
+    const bool need = walk_begin<STATS>(sc, ray, w, Ref{&slot}, cn, skip_root);
     k2_out = slot.used ? slot.v : 0xFFFFFFFFu;
     // a root that is itself a leaf still needs its triangles tested
     return need;
@@ -428,15 +448,13 @@ __device__ __forceinline__ v3 sky_lookup(const PtDeviceScene &sc, v3 d)
 {
     if (sc.sky_size == 0) return V3(0.0f, 0.0f, 0.0f);
     const float ax = pt_abs(d.x), ay = pt_abs(d.y), az = pt_abs(d.z);
-    uint32_t face;
-    float scoord, tcoord, ma;
-    if (az >= ax && az >= ay) {
-        face = d.z < 0.0f ? 5u : 4u; scoord = d.z < 0.0f ? -d.x : d.x; tcoord = -d.y; ma = az;
-    } else if (ay >= ax) {
-        face = d.y < 0.0f ? 3u : 2u; scoord = d.x; tcoord = d.y < 0.0f ? -d.z : d.z; ma = ay;
-    } else {
-        face = d.x < 0.0f ? 1u : 0u; scoord = d.x < 0.0f ? d.z : -d.z; tcoord = -d.y; ma = ax;
-    }
+    // (selects, not branches: the three cases are a few moves each, and a lane mask per case costs more)
+    const bool zmaj = az >= ax && az >= ay, ymaj = !zmaj && ay >= ax;
+    const float ma = zmaj ? az : ymaj ? ay : ax;
+    const bool neg = (zmaj ? d.z : ymaj ? d.y : d.x) < 0.0f;
+    const uint32_t face = (zmaj ? 4u : ymaj ? 2u : 0u) + (neg ? 1u : 0u);
+    const float scoord = zmaj ? (neg ? -d.x : d.x) : ymaj ? d.x : (neg ? d.z : -d.z);
+    const float tcoord = ymaj ? (neg ? -d.z : d.z) : -d.y;
     const float size = (float)sc.sky_size;
     const float inv_ma = pt_rcp(ma);
     const float fs = pt_fma(0.5f, scoord * inv_ma, 0.5f) * size;
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                 if (active) {
                     PT_FRESH_PARAMS(L);
                     cn.rays++;
-                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn) ? M_WALK : M_SHADE;
+                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
                     if (mode == M_WALK) walk_enter(w);
                 } else {
@@ -1483,7 +1501,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     bool need_walk;
                     {
                         PT_FRESH_PARAMS(L);
-                        need_walk = walk_begin_pool<STATS>(L.sc, cur, nw, k2, cn);
+                        need_walk = walk_begin_pool<STATS>(L.sc, cur, nw, k2, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y));
                     }
 #ifdef PT_DIAG
                     if (!HITS) { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
@@ -1627,7 +1645,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             bool need_walk;
                             {
                                 PT_FRESH_PARAMS(LW);
-                                need_walk = walk_begin_pool<STATS>(LW.sc, cur, nw, k2, cn);
+                                need_walk = walk_begin_pool<STATS>(LW.sc, cur, nw, k2, cn, pt_camera_ray_misses_bvh(LW.cull, x, y));  // (every ray of this loop is a camera ray)
                             }
                             if (need_walk || nw.rec.hit) {
                                 // this ray goes on elsewhere: the slot's whole state to LDS

@@ -336,3 +336,40 @@ def test_reference_dispatch_smaller_than_one_group(pt, scenes):
     r.render_frames(100, 1, 40)
     assert (r.read_sum() == 0).all() and r.stats()["rays"] == 0 and r.stats()["frames"] == 54
     r.close()
+
+
+def test_camera_ray_culling_rectangles(pt, po, scenes):
+    """Camera rays of pixels outside the screen rectangles of the root's two child boxes skip the root visit
+    (it is known to end the walk).  Cameras that stress the rectangles: far away (mesh a few pixels wide), close and
+    off-centre (a box leaves the screen on one side), inside the mesh's box (a corner behind the camera: no
+    statement), looking away (everything behind), narrow and wide fields of view, a basis that is not orthonormal,
+    an image smaller than the margin.  Radiance, primary-hit ids and ray counts must stay the oracle's."""
+    base = scenes.bunny(n=10)
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(2, 4, 1e-4, 1000.0)
+    C = pt.Camera
+    cams = [
+        (C.from_yaw_pitch((1.0, 1.0, 40.0), -90.0, 0.0, 1.0, 30.0), 96, 54),
+        (C.from_yaw_pitch((1.6, 0.6, 1.2), -100.0, -5.0, 1.0, 75.0), 96, 54),
+        (C.from_yaw_pitch((0.0, 0.5, -1.0), -90.0, 0.0, 1.0, 75.0), 64, 40),
+        (C.from_yaw_pitch((1.0, 1.0, 4.7), 90.0, 0.0, 1.0, 75.0), 64, 40),
+        (C.from_yaw_pitch((1.0, 1.0, 4.7), -90.0, 0.0, 1.0, 5.0), 64, 40),
+        (C.from_yaw_pitch((0.3, 0.8, 2.5), -95.0, -10.0, 0.5, 140.0), 96, 54),
+        (C(origin=(1.0, 1.0, 4.7), forward=(0.1, -0.05, -1.0), right=(1.0, 0.2, 0.0), up=(0.1, 1.0, 0.1), focal_length=1.3, vfov=60.0), 80, 48),
+        (C.from_yaw_pitch((1.0, 1.0, 4.7), -90.0, 0.0, 1.0, 75.0), 3, 2),
+    ]
+    for cam, w, h in cams:
+        scene = pt.Scene(base.spheres, base.triangles, cam)
+        r, osc = _pair(pt, po, scene, w, h, st, sky)
+        r.render(3)
+        gprim, _ = r.read_aov()
+        r.render_frames(10, 1, 5)
+        acc, prim, tt, s = osc.render(3, want_aov=True)
+        rays = s["rays"]
+        for f in range(5):
+            acc, _, _, s = osc.render(10 + f, acc)
+            rays += s["rays"]
+        assert np.array_equal(gprim, prim)
+        _exact(r.read_sum(), acc, f"camera at {cam.origin}")
+        assert r.stats()["rays"] == rays
+        r.close()
