@@ -1467,8 +1467,16 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 if (finished) {
                     PT_FRESH_PARAMS(L);
                     if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                } else if (HITS && retire) {
+                    // The path is over and the job goes on: the pixel's next path is started by a pass over misses (a slot
+                    // without a ray is one of theirs), where every lane starts a path, instead of here, where the few lanes
+                    // that retire would have the whole wave run the RNG and the camera ray.
+                    sh.st[F_FRAME][p] = frame;
+                    sh.st[F_FS][p] = sample << 2;
+                    sh.st[F_COST][p] = cost;
+                    to_ready = true;
                 } else {
-                    if (!had_ray || retire) {
+                    if constexpr (!HITS) if (!had_ray || retire) {
                         // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
                         PT_FRESH_PARAMS(L);
                         uint32_t sx, sy, sz, sw;

@@ -373,3 +373,33 @@ def test_camera_ray_culling_rectangles(pt, po, scenes):
         _exact(r.read_sum(), acc, f"camera at {cam.origin}")
         assert r.stats()["rays"] == rays
         r.close()
+
+
+def test_short_launch_scratch_is_bounded(pt, scenes):
+    """Launches of 2..15 frames plan one 1 KiB row of partial sums per tile and frame so that the frames run side by
+    side -- as long as those rows stay below 640 MiB; above that they run frame after frame with no rows at all.
+    Device memory in use may therefore grow by at most that much, whatever the image size, and the image is the same
+    frame-by-frame sum either way."""
+    import torch
+    scene = scenes.bunny(n=6)
+    sky = scenes.sky_cube_direct(8)
+    st = pt.Settings(1, 3, 1e-4, 1000.0)
+    for (w, h, n) in ((1920, 1080, 15), (3840, 2160, 8)):
+        r = pt.Renderer(scene, w, h, settings=st)
+        r.set_sky_cube(sky)
+        r.render(1)
+        r.sync()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        r.render_frames(2, 1, n)
+        r.sync()
+        grown = free0 - torch.cuda.mem_get_info(0)[0]
+        assert grown <= (680 << 20), f"{w}x{h}, {n} frames: {grown >> 20} MiB of scheduling memory"
+        got = r.read_sum()
+        r2 = pt.Renderer(scene, w, h, settings=st)
+        r2.set_sky_cube(sky)
+        for f in range(n + 1):
+            r2.render(1 + f)
+        same = got.view(np.uint32) == r2.read_sum().view(np.uint32)
+        assert same.all(), f"{w}x{h}: {int((~same).sum())} values differ from frame-by-frame dispatches"
+        r.close()
+        r2.close()
