@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dg_trips = 0, dg_idle = 0, dg_shades = 0, dg_ready = 0, dg_shade_cyc = 0, dg_steps = 0, dg_busy = 0, dg_walk_cyc = 0,
                        dg_claim_cyc = 0, dg_claims = 0, dg_s = 0, dg_hit_passes = 0, dg_hit_lanes = 0, dg_hit_cyc = 0, dg_s2 = 0;
-    unsigned long long dg_sec[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg_sec[7] = {0, 0, 0, 0, 0, 0, 0}, dg_rounds = 0, dg_round_lanes = 0, dg_extra[3] = {0, 0, 0};
     unsigned long long dg_hist[5] = {0, 0, 0, 0, 0};
 #endif
     // Every wave leaves the loop: normally when no slot is live any more, and in any case after
@@ -1564,6 +1564,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             // when too few lanes are left or after pool_miss_iters rounds.
             auto miss_pass = [&]() {
                 p = ring_pop(sh.ring[R_MISS], &sh.head[R_MISS], &sh.tail[R_MISS], ~0ull, lane, lt_mask, FL::PATHS);
+#ifdef PT_DIAG
+                { const unsigned long long t = clock64(); dg_sec[0] += t - dg_s; dg_s2 = t; }
+#endif
                 bool mine = p != 0xFFFFFFFFu;  // this lane still carries its slot through the loop
                 uint32_t x = 0, y = 0, frame_end = 0, pidx = 0, frame = 0, sample = 0, cost = 0;
                 bool have_ray = false, want_aov = false, dirty = false;
@@ -1602,7 +1605,14 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         rx = sh.st[FL::RNG][p]; ry = sh.st[FL::RNG + 1][p]; rz = sh.st[FL::RNG + 2][p]; rw = sh.st[FL::RNG + 3][p];  // (unused by a frame's first sample)
                     }
                 }
+#ifdef PT_DIAG
+                { const unsigned long long t = clock64(); dg_sec[1] += t - dg_s2; dg_s2 = t; }
+#endif
                 for (uint32_t round = 0;; round++) {
+#ifdef PT_DIAG
+                    dg_rounds++;
+                    dg_round_lanes += __popcll(__ballot(mine));
+#endif
                     PT_FRESH_PARAMS(L);
                     const PtDeviceScene &sc = L.sc;
                     if (mine) {
@@ -1651,10 +1661,16 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             Walk nw;
                             uint32_t k2 = 0xFFFFFFFFu;
                             bool need_walk;
+#ifdef PT_DIAG
+                            { const unsigned long long t = clock64(); dg_sec[2] += t - dg_s2; dg_s2 = t; }
+#endif
                             {
                                 PT_FRESH_PARAMS(LW);
                                 need_walk = walk_begin_pool<STATS>(LW.sc, cur, nw, k2, cn, pt_camera_ray_misses_bvh(LW.cull, x, y));  // (every ray of this loop is a camera ray)
                             }
+#ifdef PT_DIAG
+                            { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
+#endif
                             if (need_walk || nw.rec.hit) {
                                 // this ray goes on elsewhere: the slot's whole state to LDS
                                 sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
@@ -1684,6 +1700,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                                 have_ray = true;
                             }
                         }
+#ifdef PT_DIAG
+                        { const unsigned long long t = clock64(); dg_sec[4] += t - dg_s2; dg_s2 = t; }
+#endif
                         // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
                         if (retire) {
                             path_color = path_color * sky;
@@ -1698,6 +1717,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             if constexpr (!SPP1) fsum = path_color;
                         }
                     }
+#ifdef PT_DIAG
+                    { asm volatile("s_waitcnt vmcnt(0)"); const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
+#endif
                     const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine));
                     if (n_mine < PT_TUNE(L.pool_miss_lanes, PT_POOL_MISS_LANES) || round + 1u >= PT_TUNE(L.pool_miss_iters, PT_POOL_MISS_ITERS)) break;
                 }
@@ -1726,21 +1748,32 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             else if (miss_iters > 1u) miss_pass();
             else shading_pass(std::false_type{});
 #ifdef PT_DIAG
-            if (!pass_hits) { const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
+            if (!pass_hits) { const unsigned long long t = clock64(); dg_sec[6] += t - dg_s2; dg_s2 = t; }
 #endif
             const uint32_t id = p;
             // slots whose job is done take the next one (or die when the launch has no items left)
+#ifdef PT_DIAG
+            const unsigned long long dg_j0 = clock64();
+#endif
             if (__ballot(finished) != 0ull) {
                 const bool got = assign_jobs(finished, p);
                 to_ready = to_ready || (finished && got);
                 const uint32_t n_dead = (uint32_t)__popcll(__ballot(finished && !got));
                 if (n_dead && lane == 0) atomicSub(&sh.live, n_dead);
             }
+#ifdef PT_DIAG
+            const unsigned long long dg_j1 = clock64();
+            if (!pass_hits) { dg_extra[0] += dg_j1 - dg_j0; dg_extra[2] += __popcll(__ballot(finished)); }
+#endif
             ring_push3(sh.ring, sh.tail, to_ready, to_hit, to_pending, p, lane, lt_mask);
+#ifdef PT_DIAG
+            if (!pass_hits) dg_extra[1] += clock64() - dg_j1;
+#endif
             const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
             if (gotm) did_work = true;
 #ifdef PT_DIAG
             if (!pass_hits) dg_sec[6] += clock64() - dg_s2;
+
             dg_shades++;
             dg_ready += __popcll(gotm);
             dg_shade_cyc += clock64() - dg_s;
@@ -1773,8 +1806,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             g_diag_marks[(wid & 63u) * 8 + 3] = dg_shades;
             g_diag_marks[(wid & 63u) * 8 + 4] = dg_ready;
             g_diag_marks[(wid & 63u) * 8 + 5] = dg_shade_cyc;
+            g_diag_marks[(wid & 63u) * 8 + 6] = dg_rounds;
+            g_diag_marks[(wid & 63u) * 8 + 7] = dg_round_lanes;
             for (int k = 0; k < 7; k++) g_diag_marks[512 + (wid & 63u) * 8 + k] = dg_sec[k];
             for (int k = 0; k < 5; k++) g_diag_marks[1024 + (wid & 63u) * 8 + k] = dg_hist[k];
+            for (int k = 0; k < 3; k++) g_diag_marks[1024 + (wid & 63u) * 8 + 5 + k] = dg_extra[k];
             g_diag[8 * wid + 3] = dg_shades | (dg_ready << 32);
             g_diag[8 * wid + 4] = dg_shade_cyc;
             g_diag[8 * wid + 5] = dg_steps | (dg_busy << 32);

@@ -55,6 +55,7 @@ L.pt_diag_read_marks.argtypes = [C.c_void_p, C.c_size_t]
 L.pt_diag_read_marks(marks.ctypes.data_as(C.c_void_p), marks.nbytes)
 sec = marks[64:128].astype(np.float64).sum(axis=0)
 hist = marks[128:].astype(np.float64).sum(axis=0)[:5]
+extra = marks[128:].astype(np.float64).sum(axis=0)[5:8]
 print("walk steps by busy lanes [1-8, 9-16, 17-32, 33-48, 49-64]: " + " ".join(f"{100 * v / max(hist.sum(), 1):.1f}%" for v in hist))
 marks = marks[:64]
 m = marks.astype(np.float64).sum(axis=0)
@@ -63,5 +64,7 @@ if m[3] > 0:
     print("hit passes %.1f%% of passes: %.1f lanes, %.0f cycles; miss passes: %.1f lanes, %.0f cycles" % (
         100 * hp / ap, hl / max(hp, 1), hc / max(hp, 1), (al - hl) / max(ap - hp, 1), (ac - hc) / max(ap - hp, 1)))
     nm = max(ap - hp, 1)
-    names = ["pop", "load+sky issue", "counters+new path", "walk_begin", "stores", "deferred sums", "jobs+pushes"]
+    names = ["pop", "state load", "sky issue + new path", "spheres + root visit", "hand-over stores", "sky wait + sums", "write-back + jobs + pushes"]
+    print("miss pass rounds per pass %.2f, lanes per round %.1f" % (m[6] / nm, m[7] / max(m[6], 1)))
+    print("after a miss pass: job hand-out %.0f cycles per pass (%.1f lanes finished their job), ring pushes %.0f" % (extra[0] / nm, extra[2] / nm, extra[1] / nm))
     print("miss pass sections (cycles): " + ", ".join(f"{n} {v / nm:.0f}" for n, v in zip(names, sec)))
