@@ -66,6 +66,7 @@ extern "C" {
     pub fn pt_set_window(ctx: *mut PtCtx, sample_size: u32) -> i32;
     pub fn pt_read_window(ctx: *mut PtCtx, rgba32f_out: *mut f32, rgba8_out: *mut u8, frames_shown: *mut u32) -> i32;
     pub fn pt_read_aov(ctx: *mut PtCtx, prim: *mut u32, t: *mut f32) -> i32;
+    pub fn pt_read_sky_tiles(ctx: *mut PtCtx, out: *mut u32, capacity: usize, n_tiles: *mut u32) -> i32;
     pub fn pt_stats(ctx: *mut PtCtx, out: *mut PtStats) -> i32;
     pub fn pt_accum_device_ptr(ctx: *mut PtCtx) -> *mut c_void;
     pub fn pt_bind_accum(ctx: *mut PtCtx, device_ptr: *mut c_void) -> i32;

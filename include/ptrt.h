@@ -166,6 +166,12 @@ int pt_set_window(pt_ctx *ctx, uint32_t sample_size);
 int pt_read_window(pt_ctx *ctx, float *rgba32f_out, uint8_t *rgba8_out, uint32_t *frames_shown);
 /* Primary-hit primitive id and t per pixel (needs PT_FLAG_AOV during rendering). */
 int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t);
+/* Per 8x8 tile (row-major, ceil(width/8) x ceil(height/8)): 1 if the most recently planned launch found that every
+ * camera ray of the tile leaves the scene at once and summed its frames in a loop of its own (identical results,
+ * frame after frame), else 0.  All zero while no launch has been planned (one-frame calls, PT_FLAG_DETAILED_STATS,
+ * several samples per frame, depth 0).  No counterpart in the reference: a diagnostic of this backend's scheduling.
+ * *n_tiles (may be NULL) receives the tile count; with out == NULL only that; capacity below it is PT_ERR_INVALID. */
+int pt_read_sky_tiles(pt_ctx *ctx, uint32_t *out, size_t capacity, uint32_t *n_tiles);
 int pt_stats(pt_ctx *ctx, pt_stats_t *out);
 /* Device address of the accumulation buffer (for collectives on it), and a way to make the
  * renderer accumulate into caller-owned device memory of width*height*16 bytes instead. */

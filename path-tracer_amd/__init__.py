@@ -99,6 +99,7 @@ ABI = [
     ("pt_set_window", _I, [_VP, _U32]),
     ("pt_read_window", _I, [_VP, _VP, _VP, C.POINTER(_U32)]),
     ("pt_read_aov", _I, [_VP, _VP, _VP]),
+    ("pt_read_sky_tiles", _I, [_VP, _VP, C.c_size_t, C.POINTER(_U32)]),
     ("pt_stats", _I, [_VP, C.POINTER(Stats)]),
     ("pt_accum_device_ptr", _VP, [_VP]),
     ("pt_bind_accum", _I, [_VP, _VP]),
@@ -401,6 +402,14 @@ class Renderer:
         t = np.zeros((self.height, self.width), np.float32)
         self._ck(self._l.pt_read_aov(self._ctx, _ptr(prim), _ptr(t)))
         return prim, t
+
+    def read_sky_tiles(self) -> np.ndarray:
+        """(ceil(height/8), ceil(width/8)) flags: tiles the last planned launch summed in its sky-only loop."""
+        n = C.c_uint32(0)
+        self._ck(self._l.pt_read_sky_tiles(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint32)
+        self._ck(self._l.pt_read_sky_tiles(self._ctx, _ptr(out), out.size, C.byref(n)))
+        return out.reshape((self.height + 7) // 8, (self.width + 7) // 8)
 
     def stats(self) -> dict:
         s = Stats()

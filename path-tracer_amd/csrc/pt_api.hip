@@ -68,6 +68,9 @@ struct pt_ctx {
     // work-item planning (see plan_kernel)
     uint32_t *tile_cost = nullptr, *tile_sorted = nullptr, *next_item = nullptr;
     uint2 *tile_items = nullptr;
+    uint32_t *tile_sky = nullptr;  // per tile: sees only the sky (PtSchedule::tile_sky)
+    hipStream_t side_stream = nullptr;  // the sky-only tiles' loop runs here, beside the megakernel
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
     uint4 *items = nullptr;
     float4 *partial = nullptr;
     uint32_t item_cap = 0, n_tiles = 0, resident_waves = 5120;
@@ -362,7 +365,12 @@ static int pt_create_impl(int device, uint32_t width, uint32_t height, pt_ctx **
     if (rc == PT_OK) step(hipMemset(ctx->next_item, 0, 256), "clear");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sorted, n_tiles * sizeof(uint32_t)), "tile order");
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_items, n_tiles * sizeof(uint2)), "tile items");
+    if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sky, n_tiles * sizeof(uint32_t)), "tile flags");
+    if (rc == PT_OK) step(hipMemset(ctx->tile_sky, 0, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
+    if (rc == PT_OK) step(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "side stream");
+    if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming), "event");
+    if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -395,6 +403,12 @@ void pt_destroy(pt_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     dev_free(ctx->window_ring);
     dev_free(ctx->window_frame);
     dev_free(ctx->accum_owned);
@@ -412,6 +426,7 @@ void pt_destroy(pt_ctx *ctx)
     dev_free(ctx->next_item);
     dev_free(ctx->tile_sorted);
     dev_free(ctx->tile_items);
+    dev_free(ctx->tile_sky);
     dev_free(ctx->scratch);
     delete ctx;
 }
@@ -753,6 +768,11 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     sch.cost = ctx->tile_cost;
     sch.sorted = ctx->tile_sorted;
     sch.tile_items = ctx->tile_items;
+    sch.tile_sky = ctx->tile_sky;
+    sch.sky_tiles = !env_str("PTRT_NO_SKY_TILES");  // (tuning builds: A/B switches)
+    sch.side_stream = env_str("PTRT_NO_SIDE_STREAM") ? nullptr : ctx->side_stream;
+    sch.fork_event = ctx->fork_event;
+    sch.join_event = ctx->join_event;
     sch.cost_valid = &ctx->cost_valid;
     // Items per resident wave slot.  Pooled kernel: a pixel's frames run one after the other, so costly tiles need
     // short items, but every item costs 64 job hand-outs and a row of partial sums: one item per slot and four
@@ -1075,6 +1095,17 @@ static int pt_read_aov_impl(pt_ctx *ctx, uint32_t *prim, float *t)
     return PT_OK;
 }
 
+static int pt_read_sky_tiles_impl(pt_ctx *ctx, uint32_t *out, size_t capacity, uint32_t *n_tiles)
+{
+    PT_ENTER(ctx);
+    if (n_tiles) *n_tiles = ctx->n_tiles;
+    if (!out) return n_tiles ? PT_OK : fail(ctx, PT_ERR_INVALID, "pt_read_sky_tiles: null output");
+    if (capacity < ctx->n_tiles) return fail(ctx, PT_ERR_INVALID, "pt_read_sky_tiles: room for %zu tiles, the image has %u", capacity, ctx->n_tiles);
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PT_HIP(ctx, hipMemcpy(out, ctx->tile_sky, (size_t)ctx->n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 static int pt_stats_impl(pt_ctx *ctx, pt_stats_t *out)
 {
     PT_ENTER(ctx);
@@ -1331,6 +1362,16 @@ int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t)
 {
     try {
         return pt_read_aov_impl(ctx, prim, t);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_read_sky_tiles(pt_ctx *ctx, uint32_t *out, size_t capacity, uint32_t *n_tiles)
+{
+    try {
+        return pt_read_sky_tiles_impl(ctx, out, capacity, n_tiles);
     } catch (const std::bad_alloc &) {
         return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
     } catch (...) {

@@ -117,6 +117,12 @@ struct PtSchedule {
     uint32_t *cost;        // n_tiles, zero-initialised
     uint32_t *sorted;      // n_tiles
     uint2 *tile_items;     // n_tiles
+    uint32_t *tile_sky;    // n_tiles: 1 for a tile whose camera rays all provably leave the scene (set when a launch is planned)
+    bool sky_tiles;        // such tiles get no work items: their frames are summed by a loop of their own, frame after frame
+    // That loop waits on sky texels while the megakernel is bound by arithmetic, so it runs beside it on a stream
+    // of its own, forked from and joined back into the launch stream by these events (null: on the launch stream).
+    hipStream_t side_stream;
+    hipEvent_t fork_event, join_event;
     uint4 *items;          // item_cap
     float4 *partial;       // item_cap * 64
     uint32_t item_cap;

@@ -310,7 +310,9 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
     } else {
         const float4 *base = tri ? sc.tri_pos + 3 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
         // all four loads for every lane (the triangle array is padded by one float4): issued together
-        float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
+        float4 q0 = base[0], q1 = base[1], q2 = base[2];
+        float2 q3 = make_float2(0.0f, 0.0f);
+        if (!tri) q3 = *reinterpret_cast<const float2 *>(base + 3);  // the two child tokens: lanes at a triangle skip this load
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
         asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y));
@@ -561,7 +563,7 @@ __device__ __forceinline__ bool shade_ray(const PtDeviceScene &sc, Ray &cur, con
 // Diagnostic build only (make diag): per-wave start/end stamps, hardware id and loop trip count.
 #define PT_DIAG_MAX_WAVES (1u << 18)
 __device__ unsigned long long g_diag[8 * PT_DIAG_MAX_WAVES];
-__device__ unsigned long long g_diag_marks[3 * 8 * 64];  // first 64 work items: realtime at every 1024th loop trip
+__device__ unsigned long long g_diag_marks[5 * 8 * 64];  // first 64 work items: realtime at every 1024th loop trip
 #endif
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -1217,6 +1219,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                        dg_claim_cyc = 0, dg_claims = 0, dg_s = 0, dg_hit_passes = 0, dg_hit_lanes = 0, dg_hit_cyc = 0, dg_s2 = 0;
     unsigned long long dg_sec[7] = {0, 0, 0, 0, 0, 0, 0}, dg_rounds = 0, dg_round_lanes = 0, dg_extra[3] = {0, 0, 0};
     unsigned long long dg_hist[5] = {0, 0, 0, 0, 0};
+    unsigned long long dg_len_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_len_steps[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // finished walks by length
 #endif
     // Every wave leaves the loop: normally when no slot is live any more, and in any case after
     // max_idle consecutive trips without anything to do (a lost hand-shake would otherwise hang the
@@ -1322,6 +1325,17 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         fin = true;
                     }
                 }
+#ifdef PT_DIAG
+                {
+                    const bool ended = fin && !wbusy && wsteps != 0u;
+                    const uint32_t b = wsteps <= 1u ? 0 : wsteps <= 2u ? 1 : wsteps <= 4u ? 2 : wsteps <= 8u ? 3 : wsteps <= 16u ? 4 : wsteps <= 32u ? 5 : wsteps <= 64u ? 6 : 7;
+                    for (uint32_t q = 0; q < 8u; q++) {
+                        dg_len_n[q] += __popcll(__ballot(ended && b == q));
+                        dg_len_steps[q] += wave_sum((ended && b == q) ? wsteps : 0u);
+                    }
+                    if (ended) wsteps = 0;  // (counted once)
+                }
+#endif
                 if (__ballot(wbusy) == 0ull || k + 1u >= PT_TUNE(P.pool_steps, PT_POOL_STEPS)) break;
             }
             __builtin_amdgcn_s_setprio(0);
@@ -1811,6 +1825,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             for (int k = 0; k < 7; k++) g_diag_marks[512 + (wid & 63u) * 8 + k] = dg_sec[k];
             for (int k = 0; k < 5; k++) g_diag_marks[1024 + (wid & 63u) * 8 + k] = dg_hist[k];
             for (int k = 0; k < 3; k++) g_diag_marks[1024 + (wid & 63u) * 8 + 5 + k] = dg_extra[k];
+            for (int k = 0; k < 8; k++) { g_diag_marks[1536 + (wid & 63u) * 8 + k] = dg_len_n[k]; g_diag_marks[2048 + (wid & 63u) * 8 + k] = dg_len_steps[k]; }
             g_diag[8 * wid + 3] = dg_shades | (dg_ready << 32);
             g_diag[8 * wid + 4] = dg_shade_cyc;
             g_diag[8 * wid + 5] = dg_steps | (dg_busy << 32);
@@ -1860,6 +1875,108 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     if (Q.front) Q.front[i] = h.front ? 1u : 0u;
 }
 
+// ---- tiles that see nothing but the sky -----------------------------------------------------
+// In an outdoor scene most pixels' camera rays leave the scene at once.  A tile whose 64 pixels can be PROVEN to do so
+// for every jitter is taken out of the megakernels' work (no items, no path slots, no rings): its frames are summed by
+// the plain loop of sky_tiles_kernel, straight onto the running sums in frame order -- the order of the shader's own
+// frame-after-frame accumulation.  The proof is conservative and is made per pixel when a launch is planned:
+//   * mesh: the pixel lies outside the screen rectangles of the root's child boxes (PtTraceParams::cull; none if there
+//     is no mesh);
+//   * every sphere: with theta the angle between the pixel's centre ray and the direction to the sphere's centre, alpha
+//     a bound on the angle between the centre ray and any jittered ray of the pixel, L the distance of the centre and
+//     r the radius (camera outside: L > r), either every ray points away from the centre (theta - alpha > pi/2: hitSphere,
+//     compute.wgsl:304-350, then has b > 0 and c > 0, so sqrt(b^2 - 4ac) <= b in float arithmetic as well and both roots
+//     are <= 0 <= t_min), or every ray's line passes the sphere (sin^2 > (r/L)^2 over [theta - alpha, theta + alpha]:
+//     discriminant < 0).  Double arithmetic here against the kernels' float: the margins (1e-3 rad, 1e-5 in sin^2, the
+//     rounding of the float direction added to alpha) are more than ten times the float evaluation's error bounds.
+__device__ bool pt_pixel_sees_only_sky(const PtTraceParams &P, uint32_t x, uint32_t y)
+{
+    const PtDeviceScene &sc = P.sc;
+    if (sc.n_nodes != 0u && !pt_camera_ray_misses_bvh(P.cull, x, y)) return false;
+    if (sc.n_spheres == 0u) return true;
+    if (!(sc.t_min >= 0.0f)) return false;
+    const double o[3] = {P.fr.origin.x, P.fr.origin.y, P.fr.origin.z};
+    const double du[3] = {P.fr.du.x, P.fr.du.y, P.fr.du.z}, dv[3] = {P.fr.dv.x, P.fr.dv.y, P.fr.dv.z};
+    const double p0[3] = {P.fr.pixel00.x, P.fr.pixel00.y, P.fr.pixel00.z};
+    double dc[3];
+    for (int k = 0; k < 3; k++) dc[k] = (p0[k] + (double)x * du[k] + (double)y * dv[k]) - o[k];  // compute.wgsl:109-119 without the jitter
+    auto len = [](const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double ldc = len(dc), ldu = len(du), ldv = len(dv);
+    // the jitter moves the direction by at most half of du plus half of dv; the float evaluation of the direction is
+    // off by a few ulps of its largest intermediate
+    const double rho = 0.525 * (ldu + ldv) + 1e-6 * (len(p0) + (double)P.width * ldu + (double)P.height * ldv + len(o));
+    if (!(rho < 0.05 * ldc)) return false;
+    const double alpha = 1.1 * rho / ldc;  // asin(s) <= 1.1 s up to s = 0.05
+    const double pi = 3.14159265358979323846;
+    for (uint32_t i = 0; i < sc.n_spheres; i++) {
+        const float4 s0 = sc.spheres[3 * i];
+        const double r = fabs((double)s0.w);
+        const double oc[3] = {o[0] - (double)s0.x, o[1] - (double)s0.y, o[2] - (double)s0.z};
+        const double L = len(oc);
+        if (!(L > r * (1.0 + 1e-4)) || !(L > 0.0)) return false;  // camera inside or on the sphere (or not a number)
+        double c = -(oc[0] * dc[0] + oc[1] * dc[1] + oc[2] * dc[2]) / (L * ldc);
+        if (!(c == c)) return false;
+        c = fmin(fmax(c, -1.0), 1.0);
+        const double theta = acos(c), lo = theta - alpha, hi = theta + alpha;
+        const bool away = lo > 0.5 * pi + 1e-3;
+        const double sn = fmin(sin(lo), sin(hi)), q = r / L;
+        const bool clear = lo > 0.0 && hi < pi && sn * sn > q * q + 1e-5;
+        if (!(away || clear)) return false;
+    }
+    return true;
+}
+
+// One wave per tile: tile_sky[tile] = 1 if every pixel of the tile that is rendered sees only the sky.
+__global__ __launch_bounds__(256) void classify_tiles_kernel(const PtTraceParams P, uint32_t *tile_sky)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= P.n_tiles) return;
+    const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+    const uint32_t x = tbx * PT_TILE + (lane & 7u), y = tby * PT_TILE + (lane >> 3);
+    bool sky = true;
+    if (x < P.cols && y < P.rows) sky = pt_pixel_sees_only_sky(P, x, y);
+    const bool all = __ballot(!sky) == 0ull;
+    if (lane == 0) tile_sky[tile] = all ? 1u : 0u;
+}
+
+// One wave per flagged tile, one sample per frame: every frame's camera ray (compute.wgsl:85, 109-119) goes straight to the
+// sky lookup (compute.wgsl:140-143) and onto the pixel's running sums (compute.wgsl:124-127), frame after frame.  The
+// arithmetic is the megakernels' own (advance + shade_ray for a ray that hit nothing).
+// (32 registers: what four waves of the pooled kernel leave of a SIMD's 512, so that one wave of this loop fits beside them)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sky_tiles_kernel(const PtTraceParams P, const uint32_t *tile_sky)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= P.n_tiles || tile_sky[tile] == 0u) return;  // (wave-uniform)
+    const uint32_t tby = tile / P.tiles_x, tbx = tile - tby * P.tiles_x;
+    const uint32_t x = tbx * PT_TILE + (lane & 7u), y = tby * PT_TILE + (lane >> 3);
+    const bool in_image = (x < P.cols) && (y < P.rows);
+    if (in_image) {
+        const size_t pix = (size_t)y * P.width + x;
+        float4 acc = P.accum[pix];
+        const v3 ploc = v3_fma((float)y, P.fr.dv, v3_fma((float)x, P.fr.du, P.fr.pixel00));  // compute.wgsl:109
+        for (uint32_t frame = 0; frame < P.n_frames; frame++) {
+            const uint32_t time = P.time0 + frame * P.stride;
+            uint32_t sx = x, sy = y, sz = x + time, sw = y + time;  // compute.wgsl:85
+            const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+            const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+            const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
+            const v3 d = (ploc + smp) - P.fr.origin;
+            const v3 path_color = V3(1.0f, 1.0f, 1.0f) * sky_lookup(P.sc, d);
+            const v3 mean = path_color * P.inv_spp;
+            acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+        }
+        P.accum[pix] = acc;
+        if (P.aov_prim) {  // (non-null only in the launch that holds a call's first frame)
+            P.aov_prim[pix] = 0xFFFFFFFFu;
+            P.aov_t[pix] = 0.0f;
+        }
+    }
+    const uint32_t rays = wave_sum(in_image ? P.n_frames : 0u);
+    if (lane == 0 && rays) atomicAdd(&P.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH], (unsigned long long)rays);
+}
+
 // Plans the next launch from the wave time each tile cost in the previous one: tiles sorted
 // costliest first (1024 linear buckets; ties in arbitrary order), each split into
 // ceil(cost / target) items of consecutive frames, target = total cost / wanted item count, and into
@@ -1867,12 +1984,13 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
 // frame count bounds how long it takes no matter how cheap its tile is), but never into items of fewer
 // than min_chunk frames (every item has a fixed cost: a partial-sum row, a job hand-out per pixel).
 // Without cost data (first launch) every tile gets ceil(n_frames / default_chunk) items.
+// A tile flagged in tile_sky gets no items at all (sky_tiles_kernel renders it).
 // The plan only affects scheduling and the (fixed, per-plan) order of partial sums.
 // One workgroup.  tile_items[t] = (first item, item count); clears cost for the next measurement.
 __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_tiles, uint32_t n_frames, uint32_t wanted_items,
                                                     uint32_t default_chunk, uint32_t max_chunk, uint32_t min_chunk, uint4 *items,
                                                     uint32_t item_cap,
-                                                    uint2 *tile_items, uint32_t *sorted)
+                                                    uint2 *tile_items, uint32_t *sorted, const uint32_t *tile_sky)
 {
     __shared__ uint32_t hist[1024];
     __shared__ unsigned long long total;
@@ -1913,6 +2031,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(uint32_t *cost, uint32_t n_t
             n = have_cost ? (uint32_t)ceilf((float)cost[t] / target) : uniform_items;
             if (max_chunk) n = max(n, (n_frames + max_chunk - 1u) / max_chunk);
             n = min(max(n, 1u), max(n_frames / max(min_chunk, 1u), 1u));
+            if (tile_sky && tile_sky[t]) n = 0;  // rendered by sky_tiles_kernel
         }
         // block-wide exclusive scan of n (reuse hist)
         hist[tid] = n;
@@ -2192,9 +2311,16 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
     if (cap > sch.item_cap || (spills && p.gstack_blocks < cap)) return hipErrorInvalidValue;
+    // Tiles that see only the sky (one sample per frame, no per-ray statistics): flagged when the launch is planned,
+    // left out of the plan, rendered by sky_tiles_kernel.  A plan that is run again keeps its flags.
+    const bool sky_tiles = sch.sky_tiles && sch.tile_sky && p.spp == 1u && p.depth >= 1u && !detailed_stats;
     if (!sch.reuse_plan) {
+        if (sky_tiles) {
+            hipLaunchKernelGGL(classify_tiles_kernel, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, stream, p, sch.tile_sky);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        } else if (sch.tile_sky && (e = hipMemsetAsync(sch.tile_sky, 0, (size_t)p.n_tiles * sizeof(uint32_t), stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, stream, sch.cost, p.n_tiles, p.n_frames, sch.wanted_items, sch.default_chunk, sch.max_chunk,
-                           sch.min_chunk, sch.items, cap, sch.tile_items, sch.sorted);
+                           sch.min_chunk, sch.items, cap, sch.tile_items, sch.sorted, sky_tiles ? sch.tile_sky : nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.cost = sch.cost;  // cleared by plan_kernel, refilled by this launch for the next plan
     } else if (sch.measure_cost) {
@@ -2203,9 +2329,22 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     p.items = sch.items;
     p.partial = sch.partial;
+    // The megakernel first (its workgroups take their places), then the sky loop into what is left of every CU.
+    const bool beside = sky_tiles && sch.side_stream && sch.fork_event && sch.join_event && p.cols != 0 && p.rows != 0;
+    if (beside && (e = hipEventRecord(sch.fork_event, stream)) != hipSuccess) return e;
     e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
     if (e != hipSuccess) return e;
     if (p.cols == 0 || p.rows == 0) return hipSuccess;  // image smaller than one 16x16 group under PT_FLAG_REFERENCE_DISPATCH: no pixel is rendered
+    if (sky_tiles) {
+        const hipStream_t ss = beside ? sch.side_stream : stream;
+        if (beside && (e = hipStreamWaitEvent(ss, sch.fork_event, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sky_tiles_kernel, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (beside) {
+            if ((e = hipEventRecord(sch.join_event, ss)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, sch.join_event, 0)) != hipSuccess) return e;
+        }
+    }
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
                        sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
     return hipGetLastError();

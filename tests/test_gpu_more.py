@@ -403,3 +403,77 @@ def test_short_launch_scratch_is_bounded(pt, scenes):
         assert same.all(), f"{w}x{h}: {int((~same).sum())} values differ from frame-by-frame dispatches"
         r.close()
         r2.close()
+
+
+def test_sky_only_tiles(pt, po, scenes):
+    """Planned launches sum the tiles whose camera rays provably all leave the scene in a loop of their own,
+    frame after frame.  Cameras that stress the proof: above a huge ground sphere with the horizon in view (rays that
+    point at the sphere's side of the camera but pass it), looking up (everything behind), level with a small
+    sphere, inside a sphere (no statement), a sphere whose silhouette grazes tile borders, no mesh, no spheres,
+    PT_FLAG_REFERENCE_DISPATCH.  Radiance (bit for bit in launches of fewer than 16 frames), primary-hit ids and ray
+    counts must stay the oracle's, and the flagged tiles must be exactly tiles without any primary hit."""
+    S, M, C = pt.Sphere, pt.Material, pt.Camera
+    mesh = scenes.bunny(n=8).triangles
+    none = mesh[:0]
+    ground = S((0.0, -100.5, -1.0), 100.0, (0.8, 0.8, 0.0), M.Diffuse)
+    small = S((0.4, 0.9, -1.2), 0.35, (0.7, 0.2, 0.2), M.Metal)
+    glass = S((-0.9, 0.3, -0.6), 0.3, (1.0, 1.0, 1.0), M.Dielectric)
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(1, 5, 1e-4, 1000.0)
+    cases = [
+        ([ground], mesh, scenes.default_camera(), 160, 96, 0, True),
+        ([ground, small, glass], mesh, C.from_yaw_pitch((0.5, 1.4, 3.5), -95.0, -6.0), 160, 96, 0, True),
+        ([ground, small], none, C.from_yaw_pitch((0.0, 0.4, 2.0), -90.0, 35.0), 96, 56, 0, True),      # looking up
+        ([small], none, C.from_yaw_pitch((0.4, 0.9, 2.0), -90.0, 0.0, 1.0, 40.0), 128, 72, 0, True),   # one small sphere
+        ([S((0.0, 0.0, 0.0), 50.0, (0.5, 0.5, 0.5), M.Diffuse)], none, C.from_yaw_pitch((0.0, 1.0, 3.0), -90.0, 0.0), 64, 40, 0, False),  # inside
+        ([], mesh, scenes.default_camera(), 128, 72, 0, True),                                          # mesh only
+        ([], none, scenes.default_camera(), 64, 40, 0, True),                                           # nothing at all
+        ([ground, small], mesh, scenes.default_camera(), 100, 59, pt.PT_FLAG_REFERENCE_DISPATCH, True),
+    ]
+    for spheres, tris, cam, w, h, flags, expect_some in cases:
+        scene = pt.Scene(spheres, tris, cam)
+        osc = po.from_scene(scene, w, h, st, sky, po.FLAG_REFERENCE_DISPATCH if flags & pt.PT_FLAG_REFERENCE_DISPATCH else 0)
+        r = pt.Renderer(scene, w, h, settings=st, flags=pt.PT_FLAG_AOV | flags)
+        r.set_sky_cube(sky)
+        # first call: four frames straight (no cost measurement yet), the rest planned; second call: planned, with the AOV
+        r.render_frames(1, 1, 9)
+        r.reset_ready_samples()
+        r.render_frames(20, 1, 7)
+        flagged = r.read_sky_tiles().astype(bool)
+        gprim, gt = r.read_aov()
+        got = r.read_sum()
+        acc, prim, tt, s = osc.render(20, want_aov=True)
+        rays = s["rays"]
+        for f in range(1, 7):
+            acc, _, _, s = osc.render(20 + f, acc)
+            rays += s["rays"]
+        what = f"{len(spheres)} spheres, {len(tris)} triangles, {w}x{h}, flags {flags:#x}"
+        assert np.array_equal(gprim, prim) and np.array_equal(gt.view(np.uint32), tt.view(np.uint32)), what
+        assert np.array_equal(got.view(np.uint32), acc.view(np.uint32)), what
+        assert r.stats()["rays"] == rays, what
+        assert flagged.any() == expect_some, what
+        # a flagged tile has no primary hit in any of its rendered pixels
+        hit = prim != 0xFFFFFFFF
+        ty, tx = np.nonzero(flagged)
+        for a, b in zip(ty, tx):
+            assert not hit[a * 8:a * 8 + 8, b * 8:b * 8 + 8].any(), what
+        # a long launch (sums regrouped for the other tiles) agrees up to summation order, and exactly in flagged tiles
+        r.reset_ready_samples()
+        r.render_frames(100, 1, 24)
+        got = r.read_sum()
+        acc = None
+        for f in range(24):
+            acc, _, _, _ = osc.render(100 + f, acc) if acc is not None else osc.render(100 + f)
+        np.testing.assert_allclose(got, acc, rtol=24 * 2.0 ** -23, atol=1e-6, err_msg=what)
+        mask = np.kron(r.read_sky_tiles(), np.ones((8, 8), np.uint32))[:h, :w].astype(bool)
+        assert np.array_equal(got[mask].view(np.uint32), acc[mask].view(np.uint32)), what
+        r.close()
+    # several samples per frame, per-ray statistics and one-frame calls leave every tile to the megakernels
+    scene = pt.Scene([ground], mesh, scenes.default_camera())
+    for st2, flags in ((pt.Settings(2, 5, 1e-4, 1000.0), 0), (st, pt.PT_FLAG_DETAILED_STATS)):
+        r = pt.Renderer(scene, 96, 56, settings=st2, flags=flags)
+        r.set_sky_cube(sky)
+        r.render_frames(1, 1, 9)
+        r.render_frames(20, 1, 7)
+        assert not r.read_sky_tiles().any()
+        r.close()

@@ -50,13 +50,17 @@ if ws is not None:
     srt = np.sort(ws, axis=1)[:, ::-1]
     print("walk steps by rank within the group (most-walking wave first): " + " ".join(f"{v:.0f}" for v in srt.mean(axis=0)))
 
-marks = np.zeros((192, 8), np.uint64)
+marks = np.zeros((320, 8), np.uint64)
 L.pt_diag_read_marks.argtypes = [C.c_void_p, C.c_size_t]
 L.pt_diag_read_marks(marks.ctypes.data_as(C.c_void_p), marks.nbytes)
 sec = marks[64:128].astype(np.float64).sum(axis=0)
-hist = marks[128:].astype(np.float64).sum(axis=0)[:5]
-extra = marks[128:].astype(np.float64).sum(axis=0)[5:8]
+hist = marks[128:192].astype(np.float64).sum(axis=0)[:5]
+extra = marks[128:192].astype(np.float64).sum(axis=0)[5:8]
+len_n = marks[192:256].astype(np.float64).sum(axis=0)
+len_steps = marks[256:320].astype(np.float64).sum(axis=0)
 print("walk steps by busy lanes [1-8, 9-16, 17-32, 33-48, 49-64]: " + " ".join(f"{100 * v / max(hist.sum(), 1):.1f}%" for v in hist))
+print("finished walks by steps [1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65+]: " + " ".join(f"{100 * v / max(len_n.sum(), 1):.1f}%" for v in len_n))
+print("  their share of all lane-steps:                                  " + " ".join(f"{100 * v / max(len_steps.sum(), 1):.1f}%" for v in len_steps) + f"   (mean {len_steps.sum() / max(len_n.sum(), 1):.1f} steps per walk)")
 marks = marks[:64]
 m = marks.astype(np.float64).sum(axis=0)
 if m[3] > 0:
