@@ -846,6 +846,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     }
 }
 
+#ifndef PT_INLINE_SPHERE_HITS
+#define PT_INLINE_SPHERE_HITS 1
+#endif
+
 // ---- the pooled megakernel -----------------------------------------------------------------
 // Same per-ray arithmetic as trace_kernel, different division of labour.  In an outdoor scene only
 // about one ray in ten needs a real BVH walk and those walks are long, so a wave that walks its own
@@ -1685,6 +1689,38 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
                             { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
 #endif
+                            // A primary ray that hits a sphere without needing a walk (the ground of an outdoor scene) is shaded
+                            // right here, and its bounce ray gets its spheres + root visit too: if that one leaves the scene as
+                            // well, the path never touches LDS or a ring, and the bounce ray is the miss this lane carries into
+                            // the next round.  Tried on copies and kept only if the path goes on with a bounce ray (one that ends
+                            // at the hit -- absorbed, out of bounces, a gizmo ring -- goes to a pass over hits like every other hit).
+                            v3 lcol = V3(1.0f, 1.0f, 1.0f), lidir = cur.d;
+                            uint32_t lbounce = 0, llimit = 0;
+                            if constexpr (GIZMO) llimit = L.depth;
+                            if constexpr (PT_INLINE_SPHERE_HITS && !STATS && SPP1) {
+                                if (!need_walk && nw.rec.hit) {
+                                    PT_FRESH_PARAMS(LS);
+                                    Ray br = cur;
+                                    v3 bcol = lcol, result = V3(0.0f, 0.0f, 0.0f);
+                                    uint32_t bb = 0, blimit = LS.depth, prim = 0;
+                                    const bool path_done = shade_ray<STATS, GIZMO>(LS.sc, br, nw.rec, bcol, seed, bb, blimit, cur.d, result, prim, cn);
+                                    if (!path_done && bb < blimit) {
+                                        if (want_aov) {
+                                            LS.aov_prim[(size_t)y * LS.width + x] = prim;
+                                            LS.aov_t[(size_t)y * LS.width + x] = nw.rec.t;
+                                            want_aov = false;
+                                        }
+                                        cur = br;
+                                        lcol = bcol;
+                                        lbounce = bb;
+                                        if constexpr (GIZMO) llimit = blimit;
+                                        cn.rays++;
+                                        k2 = 0xFFFFFFFFu;
+                                        PT_FRESH_PARAMS(LW);
+                                        need_walk = walk_begin_pool<STATS>(LW.sc, cur, nw, k2, cn, false);
+                                    }
+                                }
+                            }
                             if (need_walk || nw.rec.hit) {
                                 // this ray goes on elsewhere: the slot's whole state to LDS
                                 sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
@@ -1693,24 +1729,24 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                                 sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
                                 sh.st[F_U][p] = need_walk ? nw.node : 0u;
                                 sh.st[F_V][p] = need_walk ? k2 : 0u;
-                                sh.st[F_COLR][p] = __float_as_uint(1.0f); sh.st[F_COLG][p] = __float_as_uint(1.0f); sh.st[F_COLB][p] = __float_as_uint(1.0f);
+                                sh.st[F_COLR][p] = __float_as_uint(lcol.x); sh.st[F_COLG][p] = __float_as_uint(lcol.y); sh.st[F_COLB][p] = __float_as_uint(lcol.z);
                                 sh.st[F_SEED][p] = __float_as_uint(seed);
-                                sh.st[F_BOUNCE][p] = 0u;
+                                sh.st[F_BOUNCE][p] = lbounce;
                                 sh.st[F_FRAME][p] = frame;
                                 sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
                                 sh.st[F_COST][p] = cost;
                                 if constexpr (GIZMO) {
-                                    sh.st[FL::IDIR][p] = __float_as_uint(cur.d.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(cur.d.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(cur.d.z);
-                                    sh.st[FL::LIMIT][p] = L.depth;
+                                    sh.st[FL::IDIR][p] = __float_as_uint(lidir.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(lidir.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(lidir.z);
+                                    sh.st[FL::LIMIT][p] = llimit;
                                 }
                                 if constexpr (!SPP1) { sh.st[FL::RNG][p] = rx; sh.st[FL::RNG + 1][p] = ry; sh.st[FL::RNG + 2][p] = rz; sh.st[FL::RNG + 3][p] = rw; }
                                 to_pending = need_walk;
                                 to_hit = !need_walk;
                                 mine = false;
                             } else {
-                                // another miss: stays in this lane's registers
+                                // a miss (of the primary ray, or of the bounce ray off a sphere): stays in this lane's registers
                                 d = cur.d;
-                                color = V3(1.0f, 1.0f, 1.0f);
+                                color = lcol;
                                 have_ray = true;
                             }
                         }
