@@ -778,16 +778,18 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     // short items, but every item costs 64 job hand-outs and a row of partial sums: one item per slot and four
     // frames of the launch, at most 64 (bench scene, Grays/s: 64 frames 26.2 / 27.8 / 30.6 / 30.3 at 8 / 10 / 16 / 21;
     // 128 frames 33.4 / 34.2 / 34.2 / 33.7 at 16 / 21 / 32 / 42; 256 frames 33.7 / 35.0 / 35.6 / 34.9 / 33.6 at
-    // 32 / 42 / 64 / 96 / 128; 512 frames 36.1 / 36.6 / 35.2 at 64 / 85 / 128).  Per-tile kernel: every item costs a
-    // wave its start-up and its ragged end.
+    // 32 / 42 / 64 / 96 / 128; 512 frames 36.1 / 36.6 / 35.2 at 64 / 85 / 128; with the sky-only tiles out of the plan
+    // and sphere hits shaded in the pass over misses, 256 frames: 43.0 / 44.8 / 46.2 / 46.2 / 45.7 / 43.4 at
+    // 24 / 32 / 40 / 48 / 56 / 96 with items of at least 2 frames, 44.6 at 64 with at least 4).  Per-tile kernel: every
+    // item costs a wave its start-up and its ragged end.
     // A frame of several samples per pixel counts as that many frames here.
     const uint32_t spp = std::max(ctx->settings.samples_per_pixel, 1u);
     const uint32_t launch_samples = (uint32_t)std::min<uint64_t>((uint64_t)launch_frames * spp, 1u << 20);
-    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_samples / 4u, 6u), 64u) : 2);
+    const uint32_t per_slot = env_u32("PTRT_ITEMS_PER_SLOT", use_pool ? std::min(std::max(launch_samples / 4u, 6u), 48u) : 2);
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
-    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? std::max(4u / spp, 1u) : 1);
+    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? (spp == 1u ? 2u : std::max(4u / spp, 1u)) : 1);
     // Launches of 2..15 frames: one work item per tile AND frame, the items' single-frame sums added in frame order,
     // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
     // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).
