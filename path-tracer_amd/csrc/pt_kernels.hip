@@ -310,9 +310,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
     } else {
         const float4 *base = tri ? sc.tri_pos + 3 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
         // all four loads for every lane (the triangle array is padded by one float4): issued together
-        float4 q0 = base[0], q1 = base[1], q2 = base[2];
-        float2 q3 = make_float2(0.0f, 0.0f);
-        if (!tri) q3 = *reinterpret_cast<const float2 *>(base + 3);  // the two child tokens: lanes at a triangle skip this load
+        float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
         asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y));
@@ -782,7 +780,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                 if (active) {
                     PT_FRESH_PARAMS(L);
                     cn.rays++;
-                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
+                                        mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
                     if (mode == M_WALK) walk_enter(w);
                 } else {

@@ -53,12 +53,25 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if is_mega(r.get("Kernel_Name", "")) and is_planned(r["Kernel_Name"]) and "_kernel<false" in r["Kernel_Name"] and r["Counter_Name"] == name]
     big = [x for x in xs if x > 0.5 * max(xs)] if xs else []
     vals[name] = sum(big) / len(big) if big else None
+# The launch's other kernels: the sky-only tiles' loop (it runs beside the megakernel) and the addition of the partial sums.
+side = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for kern in ("sky_tiles_kernel", "accumulate_kernel"):
+        xs = []
+        for f in glob.glob(os.path.join(root, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True):
+            xs += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kern in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
+        big = [x for x in xs if x > 0.5 * max(xs)] if xs and max(xs) > 0 else []
+        side[(name, kern)] = sum(big) / len(big) if big else 0.0
+print("== per launch, KB:", {f"{k[1]} {k[0]}": round(v) for k, v in side.items()}, "megakernel", vals)
 if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals[name] += side[(name, "sky_tiles_kernel")] + side[(name, "accumulate_kernel")]
     args = sys.argv[2:]
     frames = int(args[args.index("--frames") + 1]) if "--frames" in args else 256
     workload = args[args.index("--workload") + 1] if "--workload" in args else "bunny_1080p_d8_spp256"
     rec = {"workload": workload, "frames": frames, "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
            "hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0,
+           "kernels": "megakernel + sky_tiles_kernel + accumulate_kernel of one planned launch",
            "correction": "2 x FETCH_SIZE (128-B read requests tallied at 64 B on gfx950) + WRITE_SIZE"}
     json.dump(rec, open(os.path.join(root, "pmc_traffic.json"), "w"))
     print("== traffic:", rec)
