@@ -271,7 +271,7 @@ def r_uses_pool(pt, scene, settings, frames_per_launch: int) -> bool:
     tris, spp = len(scene.triangles), max(settings.samples_per_pixel, 1)
     samples = frames_per_launch * spp
     if spp == 1:
-        return (tris >= 8192 and frames_per_launch >= 48) or (tris >= 512 and frames_per_launch >= 96)
+        return tris >= 128 and frames_per_launch >= 16
     return (tris >= 8192 and samples >= 48 and (frames_per_launch == 1 or frames_per_launch >= 16)) or \
            (tris >= 2048 and samples >= 192 and frames_per_launch >= 16)
 

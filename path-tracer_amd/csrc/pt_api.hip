@@ -706,15 +706,13 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     p.aov_prim = (ctx->flags & PT_FLAG_AOV) ? ctx->aov_prim : nullptr;
     p.aov_t = ctx->aov_t;
     p.counters = ctx->counters;
-    // Which megakernel: the pooled one pays a fixed price per ray (path state in LDS, rings, sums in
-    // global memory), needs a long launch to fill its path pool, and its spp > 1 variants run at three
-    // waves per SIMD instead of four.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled /
-    // per-tile, best of three launches): 1 spp, 16 frames per launch: 0.8 at every size; 32 frames: 0.8 up to 3k
-    // triangles, 1.0 from 12k on; 64 frames: 0.8 up to 3k, 1.06-1.15 from 12k on; 96-128 frames: 0.9-1.0 up to 3k,
-    // 1.1-1.4 from 12k on; 192 frames: 1.03 at 192 triangles, 1.07-1.16 from 768 to 28k, 1.27 at 69k; 2 spp: 0.89
-    // at 3k, 0.95 at 69k, 0.96 at 10 M with 320 path slots per workgroup; no triangles at all: 0.73.  Hence, at one
-    // sample per frame: meshes of some size in launches of 48 frames or more, any mesh worth the name in launches of
-    // 192 or more.
+    // Which megakernel: the pooled one needs a launch long enough to fill its path pool and to plan by measured cost
+    // (16 frames), and its spp > 1 variants run at three waves per SIMD instead of four and without the one-sample
+    // variants' short cuts.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled / per-tile, best of three
+    // launches; profiles/r02/kernel_choice_scan_final.txt), one sample per frame: 2-12 frames 0.35-0.57 at every mesh
+    // size; 16 frames 1.01-1.21; 32 frames 1.14-1.52; 96 frames 1.48-1.68; no triangles at all 0.95, Cornell (10
+    // triangles, 16 spp) 0.83.  Several samples per frame (round 1 and early round 2): 2 spp 0.89 at 3 k triangles, 0.95
+    // at 69 k, 0.96 at 10 M.
     // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
     // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
@@ -729,10 +727,9 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     const uint64_t samples_now = (uint64_t)launch_frames * spp_now;
     bool use_pool;
     if (spp_now == 1u)
-        use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
-                   (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES_LONG && launch_frames >= PT_POOL_LONG_FRAMES);
+        use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES;
     else
-        use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && samples_now >= PT_POOL_MIN_FRAMES &&
+        use_pool = (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES && samples_now >= PT_POOL_MULTI_MIN_SAMPLES &&
                     (launch_frames == 1u || launch_frames >= PT_POOL_MULTI_MIN_FRAMES)) ||
                    (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES_LONG && samples_now >= PT_POOL_MULTI_LONG_SAMPLES &&
                     launch_frames >= PT_POOL_MULTI_MIN_FRAMES);

@@ -19,18 +19,18 @@
 // summed by the host.
 #define PT_COUNTER_STRIPES 256u
 #define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
-// At one sample per pixel and frame the pooled kernel takes launches on meshes of at least
-// PT_POOL_MIN_TRIANGLES of at least PT_POOL_MIN_FRAMES frames, and on meshes of at least
-// PT_POOL_MIN_TRIANGLES_LONG of at least PT_POOL_LONG_FRAMES frames (pooled / per-tile, 1080p, depth 8: 96 frames
-// 0.99 at 192 triangles, 1.14 at 768, 1.02 at 3 k, 1.23 from 8.7 k on; 48 frames 1.02 at 768, 0.86 at 3 k, 1.12-1.24
-// from 8.7 k on; 32 frames 0.97-1.08 from 8.7 k on).
-#define PT_POOL_MIN_TRIANGLES 8192u
-#define PT_POOL_MIN_FRAMES 48u
-#define PT_POOL_MIN_TRIANGLES_LONG 512u
-#define PT_POOL_LONG_FRAMES 96u
-// With several samples per pixel and frame the same rule counts samples per launch instead of frames, for launches
-// of one frame or of at least PT_POOL_MULTI_MIN_FRAMES, and asks PT_POOL_MULTI_MIN_TRIANGLES_LONG triangles and
-// PT_POOL_MULTI_LONG_SAMPLES samples of a long launch.
+// At one sample per pixel and frame the pooled kernel takes launches of at least PT_POOL_MIN_FRAMES frames on meshes
+// of at least PT_POOL_MIN_TRIANGLES (pooled / per-tile, 1080p, depth 8, 192 to 69 k triangles: 16 frames 1.01-1.21,
+// 24 frames 1.01-1.38, 32 frames 1.14-1.52, 48 frames 1.31-1.53, 96 frames 1.48-1.68; 2 to 12 frames 0.35-0.57; no
+// triangles at all 0.95, ten triangles at 16 samples per frame 0.83).
+#define PT_POOL_MIN_TRIANGLES 128u
+#define PT_POOL_MIN_FRAMES 16u
+// With several samples per pixel and frame (no shading of sphere hits in the pass over misses, no sky-only tiles) the
+// rule counts samples per launch instead of frames: at least PT_POOL_MULTI_MIN_SAMPLES on meshes of at least
+// PT_POOL_MULTI_MIN_TRIANGLES, or PT_POOL_MULTI_LONG_SAMPLES on meshes of at least PT_POOL_MULTI_MIN_TRIANGLES_LONG,
+// in launches of one frame or (the second clause: only) of at least PT_POOL_MULTI_MIN_FRAMES.
+#define PT_POOL_MULTI_MIN_TRIANGLES 8192u
+#define PT_POOL_MULTI_MIN_SAMPLES 48u
 #define PT_POOL_MULTI_MIN_FRAMES 16u
 #define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
 #define PT_POOL_MULTI_LONG_SAMPLES 192u
