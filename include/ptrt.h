@@ -169,7 +169,7 @@ int pt_read_aov(pt_ctx *ctx, uint32_t *prim, float *t);
 /* Per 8x8 tile (row-major, ceil(width/8) x ceil(height/8)): 1 if the most recently planned launch found that every
  * camera ray of the tile leaves the scene at once and summed its frames in a loop of its own (identical results,
  * frame after frame), else 0.  All zero while no launch has been planned (one-frame calls, PT_FLAG_DETAILED_STATS,
- * several samples per frame, depth 0).  No counterpart in the reference: a diagnostic of this backend's scheduling.
+ * depth 0).  No counterpart in the reference: a diagnostic of this backend's scheduling.
  * *n_tiles (may be NULL) receives the tile count; with out == NULL only that; capacity below it is PT_ERR_INVALID. */
 int pt_read_sky_tiles(pt_ctx *ctx, uint32_t *out, size_t capacity, uint32_t *n_tiles);
 int pt_stats(pt_ctx *ctx, pt_stats_t *out);

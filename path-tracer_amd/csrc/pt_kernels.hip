@@ -1974,10 +1974,11 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(const PtTraceParams
     if (lane == 0) tile_sky[tile] = all ? 1u : 0u;
 }
 
-// One wave per flagged tile, one sample per frame: every frame's camera ray (compute.wgsl:85, 109-119) goes straight to the
+// One wave per flagged tile: every sample's camera ray (compute.wgsl:85, 109-119) goes straight to the
 // sky lookup (compute.wgsl:140-143) and onto the pixel's running sums (compute.wgsl:124-127), frame after frame.  The
 // arithmetic is the megakernels' own (advance + shade_ray for a ray that hit nothing).
 // (32 registers: what four waves of the pooled kernel leave of a SIMD's 512, so that one wave of this loop fits beside them)
+template <bool SPP1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sky_tiles_kernel(const PtTraceParams P, const uint32_t *tile_sky)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1993,12 +1994,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sky_
         for (uint32_t frame = 0; frame < P.n_frames; frame++) {
             const uint32_t time = P.time0 + frame * P.stride;
             uint32_t sx = x, sy = y, sz = x + time, sw = y + time;  // compute.wgsl:85
-            const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-            const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
-            const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
-            const v3 d = (ploc + smp) - P.fr.origin;
-            const v3 path_color = V3(1.0f, 1.0f, 1.0f) * sky_lookup(P.sc, d);
-            const v3 mean = path_color * P.inv_spp;
+            v3 frame_sum = V3(0.0f, 0.0f, 0.0f);
+            for (uint32_t sample = 0; sample < (SPP1 ? 1u : P.spp); sample++) {  // compute.wgsl:112-122; one RNG stream per pixel and frame
+                const float px = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                const float py = -0.5f + pt_hybrid_taus(sx, sy, sz, sw);
+                const v3 smp = v3_fma(py, P.fr.dv, P.fr.du * px);
+                const v3 d = (ploc + smp) - P.fr.origin;
+                if (!SPP1) (void)pt_hybrid_taus(sx, sy, sz, sw);  // the path's seed: drawn, never used by a path that hits nothing
+                const v3 path_color = V3(1.0f, 1.0f, 1.0f) * sky_lookup(P.sc, d);
+                frame_sum = SPP1 ? path_color : frame_sum + path_color;
+            }
+            const v3 mean = frame_sum * P.inv_spp;
             acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
         }
         P.accum[pix] = acc;
@@ -2007,7 +2013,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sky_
             P.aov_t[pix] = 0.0f;
         }
     }
-    const uint32_t rays = wave_sum(in_image ? P.n_frames : 0u);
+    const uint32_t rays = wave_sum(in_image ? P.n_frames * (SPP1 ? 1u : P.spp) : 0u);
     if (lane == 0 && rays) atomicAdd(&P.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH], (unsigned long long)rays);
 }
 
@@ -2345,9 +2351,9 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     const uint32_t cap = pt_trace_item_cap(p.n_tiles, p.n_frames, sch);
     if (cap > sch.item_cap || (spills && p.gstack_blocks < cap)) return hipErrorInvalidValue;
-    // Tiles that see only the sky (one sample per frame, no per-ray statistics): flagged when the launch is planned,
+    // Tiles that see only the sky (no per-ray statistics): flagged when the launch is planned,
     // left out of the plan, rendered by sky_tiles_kernel.  A plan that is run again keeps its flags.
-    const bool sky_tiles = sch.sky_tiles && sch.tile_sky && p.spp == 1u && p.depth >= 1u && !detailed_stats;
+    const bool sky_tiles = sch.sky_tiles && sch.tile_sky && p.spp >= 1u && p.depth >= 1u && !detailed_stats;
     if (!sch.reuse_plan) {
         if (sky_tiles) {
             hipLaunchKernelGGL(classify_tiles_kernel, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, stream, p, sch.tile_sky);
@@ -2372,7 +2378,8 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     if (sky_tiles) {
         const hipStream_t ss = beside ? sch.side_stream : stream;
         if (beside && (e = hipStreamWaitEvent(ss, sch.fork_event, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(sky_tiles_kernel, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
+        if (p.spp == 1u) hipLaunchKernelGGL(sky_tiles_kernel<true>, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
+        else hipLaunchKernelGGL(sky_tiles_kernel<false>, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (beside) {
             if ((e = hipEventRecord(sch.join_event, ss)) != hipSuccess) return e;

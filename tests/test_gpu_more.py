@@ -410,7 +410,7 @@ def test_sky_only_tiles(pt, po, scenes):
     frame after frame.  Cameras that stress the proof: above a huge ground sphere with the horizon in view (rays that
     point at the sphere's side of the camera but pass it), looking up (everything behind), level with a small
     sphere, inside a sphere (no statement), a sphere whose silhouette grazes tile borders, no mesh, no spheres,
-    PT_FLAG_REFERENCE_DISPATCH.  Radiance (bit for bit in launches of fewer than 16 frames), primary-hit ids and ray
+    PT_FLAG_REFERENCE_DISPATCH, several samples per frame.  Radiance (bit for bit in launches of fewer than 16 frames), primary-hit ids and ray
     counts must stay the oracle's, and the flagged tiles must be exactly tiles without any primary hit."""
     S, M, C = pt.Sphere, pt.Material, pt.Camera
     mesh = scenes.bunny(n=8).triangles
@@ -468,12 +468,28 @@ def test_sky_only_tiles(pt, po, scenes):
         mask = np.kron(r.read_sky_tiles(), np.ones((8, 8), np.uint32))[:h, :w].astype(bool)
         assert np.array_equal(got[mask].view(np.uint32), acc[mask].view(np.uint32)), what
         r.close()
-    # several samples per frame, per-ray statistics and one-frame calls leave every tile to the megakernels
-    scene = pt.Scene([ground], mesh, scenes.default_camera())
-    for st2, flags in ((pt.Settings(2, 5, 1e-4, 1000.0), 0), (st, pt.PT_FLAG_DETAILED_STATS)):
-        r = pt.Renderer(scene, 96, 56, settings=st2, flags=flags)
-        r.set_sky_cube(sky)
-        r.render_frames(1, 1, 9)
-        r.render_frames(20, 1, 7)
-        assert not r.read_sky_tiles().any()
-        r.close()
+    # several samples per frame: the loop draws every sample's three random numbers and sums the frame's samples first
+    scene = pt.Scene([ground, small], mesh, scenes.default_camera())
+    st3 = pt.Settings(3, 5, 1e-4, 1000.0)
+    osc = po.from_scene(scene, 128, 72, st3, sky)
+    r = pt.Renderer(scene, 128, 72, settings=st3, flags=pt.PT_FLAG_AOV)
+    r.set_sky_cube(sky)
+    r.render_frames(1, 1, 9)
+    r.reset_ready_samples()
+    r.render_frames(20, 1, 5)
+    assert r.read_sky_tiles().any()
+    acc, prim, tt, s = osc.render(20, want_aov=True)
+    rays = s["rays"]
+    for f in range(1, 5):
+        acc, _, _, s = osc.render(20 + f, acc)
+        rays += s["rays"]
+    gprim, gt = r.read_aov()
+    assert np.array_equal(gprim, prim) and np.array_equal(r.read_sum().view(np.uint32), acc.view(np.uint32)) and r.stats()["rays"] == rays
+    r.close()
+    # per-ray statistics leave every tile to the megakernels
+    r = pt.Renderer(scene, 96, 56, settings=st, flags=pt.PT_FLAG_DETAILED_STATS)
+    r.set_sky_cube(sky)
+    r.render_frames(1, 1, 9)
+    r.render_frames(20, 1, 7)
+    assert not r.read_sky_tiles().any()
+    r.close()
