@@ -9,7 +9,7 @@
 //                                   and l+1; the array is stored one node late so that every pair
 //                                   (odd, even index) is one 64-byte aligned block
 //   node_meta uint2 per node        (first, count), read only for leaves with > 7 triangles
-//   tri_pos   3 float4 per slot     {a, original index} {b-a} {c-a}, slot = position in the
+//   tri_pos   4 float4 per slot     {a, original index} {b-a} {c-a} {unused}, slot = position in the
 //                                   BVH's index permutation, so a leaf's triangles are contiguous
 //   tri_nrm   3 float4 per slot     vertex normals, touched once per closest hit
 //   sky       6*size*size float4    cube faces +X,-X,+Y,-Y,+Z,-Z
@@ -514,15 +514,16 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
         rec[2] = make_float4(a.max_corner[1], b.max_corner[1], a.max_corner[2], b.max_corner[2]);
         rec[3] = make_float4(u2f(token_of(n.left_child_index)), u2f(token_of(n.left_child_index + 1)), 0.0f, 0.0f);
     }
-    // one float4 of padding: the step-wise walk reads four float4 from a triangle's address
+    // triangles as 64-byte records like the node pairs: a walk step reads one aligned record whichever it is, and a
+    // random read of it is one 64-byte half line (48-byte records cost two of them three times in four)
     bool mesh_gizmo = false;
-    std::vector<float4> h_pos(3 * (size_t)n_idx + 1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);
+    std::vector<float4> h_pos(4 * (size_t)n_idx, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);
     for (uint32_t k = 0; k < n_idx; k++) {
         const PtTriangle &t = tris[tri_idx[k]];
         // edges as the shader computes them (compute.wgsl:353-354)
-        h_pos[3 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(tri_idx[k]));
-        h_pos[3 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], (float)t.material);
-        h_pos[3 * (size_t)k + 2] = make_float4(t.c[0] - t.a[0], t.c[1] - t.a[1], t.c[2] - t.a[2], 0.0f);
+        h_pos[4 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(tri_idx[k]));
+        h_pos[4 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], (float)t.material);
+        h_pos[4 * (size_t)k + 2] = make_float4(t.c[0] - t.a[0], t.c[1] - t.a[1], t.c[2] - t.a[2], 0.0f);
         // albedo and material ride in the spare components; read only with PT_FLAG_TRIANGLE_MATERIALS
         h_nrm[3 * (size_t)k] = make_float4(t.na[0], t.na[1], t.na[2], t.albedo[0]);
         h_nrm[3 * (size_t)k + 1] = make_float4(t.nb[0], t.nb[1], t.nb[2], t.albedo[1]);

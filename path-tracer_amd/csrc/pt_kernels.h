@@ -63,7 +63,7 @@ struct PtDeviceScene {
     uint32_t n_nodes;
     uint32_t root_token;
     float4 root_pair[4];     // the root's two children (device node format), valid if the root is interior
-    // triangles in leaf order: 3 float4 each {a, original index} {b-a, 0} {c-a, 0} / {na} {nb} {nc}
+    // triangles in leaf order: 4 float4 each {a, original index} {b-a, material} {c-a, 0} {unused} / 3 float4 each {na} {nb} {nc}
     const float4 *tri_pos;
     const float4 *tri_nrm;
     // sky cube: 6 faces of sky_size^2 RGBA32F

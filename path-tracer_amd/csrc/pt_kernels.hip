@@ -243,7 +243,7 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t slot = first + k;
-        const float4 *tp = sc.tri_pos + 3 * (size_t)slot;
+        const float4 *tp = sc.tri_pos + 4 * (size_t)slot;
         const float4 A4 = tp[0], E1 = tp[1], E2 = tp[2];
         if (STATS) cn.tri_tests++;
         const v3 e1 = f4_xyz(E1), e2 = f4_xyz(E2);
@@ -308,8 +308,8 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         w.leaf_left = m.y;
         next_node = m.y == 0u;
     } else {
-        const float4 *base = tri ? sc.tri_pos + 3 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
-        // all four loads for every lane (the triangle array is padded by one float4): issued together
+        const float4 *base = tri ? sc.tri_pos + 4 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
+        // all four loads for every lane (node pairs and triangles are both 64-byte records): issued together
         float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
@@ -427,9 +427,9 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
         h.material = 0.0f;
         if (sc.tri_materials) {  // opt-in: the record's own albedo and material (model.rs:66-67)
             h.att = V3(tn[0].w, tn[1].w, tn[2].w);
-            h.material = sc.tri_pos[3 * (size_t)c.index + 1].w;
+            h.material = sc.tri_pos[4 * (size_t)c.index + 1].w;
         }
-        h.prim = __float_as_uint(sc.tri_pos[3 * (size_t)c.index].w);
+        h.prim = __float_as_uint(sc.tri_pos[4 * (size_t)c.index].w);
     } else {
         const float4 s0 = sc.spheres[3 * c.index], s1 = sc.spheres[3 * c.index + 1];
         on = (h.p - f4_xyz(s0)) * sc.spheres[3 * c.index + 2].x;
