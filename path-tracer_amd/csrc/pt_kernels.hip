@@ -371,6 +371,96 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
     return false;
 }
 
+// The same step in two halves, for a loop that keeps the NEXT record's loads in flight while it finishes the
+// current step: walk_fetch issues the four loads of the record the walk stands at, walk_consume takes a loaded record,
+// decides where the walk goes next (an interior lane from its box tests, a lane at a triangle without looking at the
+// triangle: the next triangle of the leaf, or the stack), issues the loads of THAT record, and only then runs the
+// triangle test, whose result (closest hit, prune distance) no address depends on.
+struct WalkQ {
+    float4 q0, q1, q2, q3;
+};
+
+__device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU &w, WalkQ &q)
+{
+    const bool tri = w.leaf_left != 0u;
+    const bool big = !tri && (w.node & PT_TOKEN_LEAF) != 0u;  // a big leaf is resolved through node_meta: nothing to fetch here
+    const float4 *base = tri ? sc.tri_pos + 4 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)(big ? 0u : w.node);
+    q.q0 = base[0]; q.q1 = base[1]; q.q2 = base[2]; q.q3 = base[3];
+}
+
+// Returns true when the walk is over.  `prefetch`: wave-uniform, issue the next record's loads into qn.
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, const Ray &ray, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
+{
+    const v3 o = ray.o, d = ray.d;
+    const bool tri = w.leaf_left != 0u;
+    const uint32_t slot = w.leaf_next;
+    bool next_node = false;
+    // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
+    asm volatile("" : "+v"(q.q0.w), "+v"(q.q1.w), "+v"(q.q2.w), "+v"(q.q3.x), "+v"(q.q3.y));
+    if (!tri && (w.node & PT_TOKEN_LEAF)) {
+        // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
+        const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
+        w.leaf_next = m.x;
+        w.leaf_left = m.y;
+        next_node = m.y == 0u;
+    } else if (!tri) {
+        if (STATS) cn.interior++;
+        float d1, d2;
+        hit_aabb_pair(o, w.inv, q.q0, q.q1, q.q2, d1, d2);
+        uint32_t k1 = __float_as_uint(q.q3.x), k2 = __float_as_uint(q.q3.y);
+        {  // near child first (selects: cheaper than a lane mask around four moves)
+            const bool far_first = d1 > d2;
+            const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
+            const uint32_t kn = far_first ? k2 : k1, kf = far_first ? k1 : k2;
+            d1 = n; d2 = f; k1 = kn; k2 = kf;
+        }
+        if (d1 > w.nearest) {
+            next_node = true;
+        } else {
+            w.node = k1;
+            if (d2 < w.nearest) stack.push(w.sp++, k2);
+        }
+    } else {
+        w.leaf_next = slot + 1u;
+        w.leaf_left--;
+        next_node = w.leaf_left == 0u;
+    }
+    bool over = false;
+    if (next_node) {
+        if (w.sp == 0) over = true;
+        else w.node = stack.pop(--w.sp);
+    }
+    if (!over && (!tri || next_node)) walk_enter(w);
+    if (prefetch && !over) walk_fetch(sc, w, qn);
+    if (tri) {
+        // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction), straight-line as in walk_step_u
+        if (STATS) cn.tri_tests++;
+        const v3 e1 = f4_xyz(q.q1), e2 = f4_xyz(q.q2);
+        const v3 h = cross3(d, e2);
+        const float a = dot3(e1, h);
+        const float f = pt_rcp(a);
+        const v3 sv = o - f4_xyz(q.q0);
+        const float u = f * dot3(sv, h);
+        const v3 qq = cross3(sv, e1);
+        const float v = f * dot3(d, qq);
+        const float t = f * dot3(e2, qq);
+        const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                        !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
+        if (ok) {
+            w.rec.hit = true;
+            w.rec.is_tri = true;
+            w.rec.t = t;
+            w.rec.index = slot;
+            w.rec.u = u;
+            w.rec.v = v;
+            w.nearest = t;
+            if (STATS) cn.tri_accept++;
+        }
+    }
+    return over;
+}
+
 // walk_begin for the pooled kernel: same spheres + root visit, but the far child (if it has to be
 // visited) is returned in k2 instead of being pushed, because the walk may run on another lane.
 template <bool STATS>
@@ -844,6 +934,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     }
 }
 
+#ifndef PT_POOL_PIPELINED_WALK
+#define PT_POOL_PIPELINED_WALK 1
+#endif
 #ifndef PT_INLINE_SPHERE_HITS
 #define PT_INLINE_SPHERE_HITS 1
 #endif
@@ -1305,6 +1398,58 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             did_work = true;
             bool fin = false;
             __builtin_amdgcn_s_setprio(3);  // a walk step is short and waits on memory: let it issue ahead of shading
+#if PT_POOL_PIPELINED_WALK
+            // Two steps per trip of this loop, so that the record in hand and the record in flight swap registers
+            // without copies: each half consumes one and has the next one's loads under way before its triangle test.
+            {
+                const uint32_t max_steps = PT_TUNE(P.pool_steps, PT_POOL_STEPS);
+                WalkQ qa, qb;
+                qa.q0 = qa.q1 = qa.q2 = qa.q3 = qb.q0 = qb.q1 = qb.q2 = qb.q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (wbusy) walk_fetch(sc, w, qa);
+                auto half_step = [&](const WalkQ &have, WalkQ &next, bool last) {
+#ifdef PT_DIAG
+                    dg_steps++;
+                    dg_busy += __popcll(__ballot(wbusy));
+                    {
+                        const uint32_t nb = (uint32_t)__popcll(__ballot(wbusy));
+                        dg_hist[nb <= 8 ? 0 : nb <= 16 ? 1 : nb <= 32 ? 2 : nb <= 48 ? 3 : 4]++;
+                    }
+#endif
+                    if (wbusy) {
+                        wsteps++;
+                        if (walk_consume<STATS>(sc, wray, w, have, stack, cn, next, !last)) {
+                            const uint32_t p = wpath;
+                            sh.st[F_T][p] = __float_as_uint(w.rec.t);
+                            sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
+                            sh.st[F_U][p] = __float_as_uint(w.rec.u);
+                            sh.st[F_V][p] = __float_as_uint(w.rec.v);
+                            sh.st[F_COST][p] += wsteps;
+                            wbusy = false;
+                            fin = true;
+                        }
+                    }
+#ifdef PT_DIAG
+                    {
+                        const bool ended = fin && !wbusy && wsteps != 0u;
+                        const uint32_t b = wsteps <= 1u ? 0 : wsteps <= 2u ? 1 : wsteps <= 4u ? 2 : wsteps <= 8u ? 3 : wsteps <= 16u ? 4 : wsteps <= 32u ? 5 : wsteps <= 64u ? 6 : 7;
+                        for (uint32_t q = 0; q < 8u; q++) {
+                            dg_len_n[q] += __popcll(__ballot(ended && b == q));
+                            dg_len_steps[q] += wave_sum((ended && b == q) ? wsteps : 0u);
+                        }
+                        if (ended) wsteps = 0;  // (counted once)
+                    }
+#endif
+                };
+                for (uint32_t k = 0;; k += 2u) {  // (at least one step: no entry test to hoist)
+                    bool last = k + 1u >= max_steps;
+                    half_step(qa, qb, last);
+                    if (__ballot(wbusy) == 0ull || last) break;
+                    last = k + 2u >= max_steps;
+                    half_step(qb, qa, last);
+                    if (__ballot(wbusy) == 0ull || last) break;
+                }
+            }
+#else
             for (uint32_t k = 0;; k++) {  // (at least one step: no entry test to hoist)
 #ifdef PT_DIAG
                 dg_steps++;
@@ -1340,6 +1485,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                 if (__ballot(wbusy) == 0ull || k + 1u >= PT_TUNE(P.pool_steps, PT_POOL_STEPS)) break;
             }
+#endif
             __builtin_amdgcn_s_setprio(0);
             ring_push3(sh.ring, sh.tail, fin && !w.rec.hit, fin && w.rec.hit, false, wpath, lane, lt_mask);
             if (__ballot(fin)) {
@@ -1653,10 +1799,28 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             }
                         }
                         cost += 8u;  // a shading round weighs like eight node visits
+                        // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
+                        // (run once the next ray is set up, so that the texel has had time to arrive, and before a sphere hit of
+                        // that ray is shaded, so that the texel and the colour do not hold registers through the shading)
+                        auto add_retired = [&]() {
+                            if (retire) {
+                                path_color = path_color * sky;
+                                if constexpr (!SPP1) path_color = fsum + path_color;
+                                if (frame_ends) {
+                                    // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
+                                    const v3 mean = path_color * L.inv_spp;
+                                    acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
+                                    dirty = true;
+                                    path_color = V3(0.0f, 0.0f, 0.0f);
+                                }
+                                if constexpr (!SPP1) fsum = path_color;
+                            }
+                        };
                         if (frame == frame_end) {
                             finished = true;
                             mine = false;
                             if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                            add_retired();
                         } else {
                             // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
                             uint32_t sx = x, sy = y, sz = x + (L.time0 + frame * L.stride), sw = y + (L.time0 + frame * L.stride);  // compute.wgsl:85
@@ -1687,6 +1851,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
                             { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
 #endif
+                            add_retired();
                             // A primary ray that hits a sphere without needing a walk (the ground of an outdoor scene) is shaded
                             // right here, and its bounce ray gets its spheres + root visit too: if that one leaves the scene as
                             // well, the path never touches LDS or a ring, and the bounce ray is the miss this lane carries into
@@ -1751,19 +1916,6 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
                         { const unsigned long long t = clock64(); dg_sec[4] += t - dg_s2; dg_s2 = t; }
 #endif
-                        // the retired path's colour: into the frame's sample sum, and at the frame's end into the pixel's sums
-                        if (retire) {
-                            path_color = path_color * sky;
-                            if constexpr (!SPP1) path_color = fsum + path_color;
-                            if (frame_ends) {
-                                // compute.wgsl:124-127, accumulated instead of stored as rgba8unorm
-                                const v3 mean = path_color * L.inv_spp;
-                                acc.x += mean.x; acc.y += mean.y; acc.z += mean.z; acc.w += 1.0f;
-                                dirty = true;
-                                path_color = V3(0.0f, 0.0f, 0.0f);
-                            }
-                            if constexpr (!SPP1) fsum = path_color;
-                        }
                     }
 #ifdef PT_DIAG
                     { asm volatile("s_waitcnt vmcnt(0)"); const unsigned long long t = clock64(); dg_sec[5] += t - dg_s2; dg_s2 = t; }
