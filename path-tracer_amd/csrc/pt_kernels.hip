@@ -388,16 +388,13 @@ __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU 
     q.q0 = base[0]; q.q1 = base[1]; q.q2 = base[2]; q.q3 = base[3];
 }
 
-// Returns true when the walk is over.  `prefetch`: wave-uniform, issue the next record's loads into qn.
+// First half of a step on the loaded record q: moves the walk to where it goes next.  Returns true when the walk is
+// over.  (A lane at a triangle only counts it off here; walk_triangle tests it.)
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, const Ray &ray, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
+__device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, WalkU &w, float4 q0, float4 q1, float4 q2, float4 q3, StackT stack, Counters &cn)
 {
-    const v3 o = ray.o, d = ray.d;
     const bool tri = w.leaf_left != 0u;
-    const uint32_t slot = w.leaf_next;
     bool next_node = false;
-    // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
-    asm volatile("" : "+v"(q.q0.w), "+v"(q.q1.w), "+v"(q.q2.w), "+v"(q.q3.x), "+v"(q.q3.y));
     if (!tri && (w.node & PT_TOKEN_LEAF)) {
         // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
         const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
@@ -407,8 +404,8 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, const Ray 
     } else if (!tri) {
         if (STATS) cn.interior++;
         float d1, d2;
-        hit_aabb_pair(o, w.inv, q.q0, q.q1, q.q2, d1, d2);
-        uint32_t k1 = __float_as_uint(q.q3.x), k2 = __float_as_uint(q.q3.y);
+        hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
+        uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
         {  // near child first (selects: cheaper than a lane mask around four moves)
             const bool far_first = d1 > d2;
             const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
@@ -422,7 +419,7 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, const Ray 
             if (d2 < w.nearest) stack.push(w.sp++, k2);
         }
     } else {
-        w.leaf_next = slot + 1u;
+        w.leaf_next++;
         w.leaf_left--;
         next_node = w.leaf_left == 0u;
     }
@@ -432,32 +429,49 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, const Ray 
         else w.node = stack.pop(--w.sp);
     }
     if (!over && (!tri || next_node)) walk_enter(w);
-    if (prefetch && !over) walk_fetch(sc, w, qn);
-    if (tri) {
-        // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction), straight-line as in walk_step_u
-        if (STATS) cn.tri_tests++;
-        const v3 e1 = f4_xyz(q.q1), e2 = f4_xyz(q.q2);
-        const v3 h = cross3(d, e2);
-        const float a = dot3(e1, h);
-        const float f = pt_rcp(a);
-        const v3 sv = o - f4_xyz(q.q0);
-        const float u = f * dot3(sv, h);
-        const v3 qq = cross3(sv, e1);
-        const float v = f * dot3(d, qq);
-        const float t = f * dot3(e2, qq);
-        const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
-                        !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
-        if (ok) {
-            w.rec.hit = true;
-            w.rec.is_tri = true;
-            w.rec.t = t;
-            w.rec.index = slot;
-            w.rec.u = u;
-            w.rec.v = v;
-            w.nearest = t;
-            if (STATS) cn.tri_accept++;
-        }
+    return over;
+}
+
+// Second half, for a lane that stood at triangle `slot` with its record in q: hitTriangle, compute.wgsl:352-392 (edges
+// precomputed: same subtraction), straight-line as in walk_step_u.
+template <bool STATS>
+__device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, float4 q0, float4 q1, float4 q2, uint32_t slot, Counters &cn)
+{
+    if (STATS) cn.tri_tests++;
+    const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
+    const v3 h = cross3(d, e2);
+    const float a = dot3(e1, h);
+    const float f = pt_rcp(a);
+    const v3 sv = o - f4_xyz(q0);
+    const float u = f * dot3(sv, h);
+    const v3 qq = cross3(sv, e1);
+    const float v = f * dot3(d, qq);
+    const float t = f * dot3(e2, qq);
+    const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
+                    !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
+    if (ok) {
+        w.rec.hit = true;
+        w.rec.is_tri = true;
+        w.rec.t = t;
+        w.rec.index = slot;
+        w.rec.u = u;
+        w.rec.v = v;
+        w.nearest = t;
+        if (STATS) cn.tri_accept++;
     }
+}
+
+// A whole step: advance, the next record's loads (`prefetch` is wave-uniform), triangle test.  True when the walk is over.
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
+{
+    const bool tri = w.leaf_left != 0u;
+    const uint32_t slot = w.leaf_next;
+    // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
+    asm volatile("" : "+v"(q.q0.w), "+v"(q.q1.w), "+v"(q.q2.w), "+v"(q.q3.x), "+v"(q.q3.y));
+    const bool over = walk_advance<STATS>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn);
+    if (prefetch && !over) walk_fetch(sc, w, qn);
+    if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
     return over;
 }
 
@@ -870,7 +884,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                 if (active) {
                     PT_FRESH_PARAMS(L);
                     cn.rays++;
-                                        mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
+                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
                     if (mode == M_WALK) walk_enter(w);
                 } else {
@@ -1417,7 +1431,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                     if (wbusy) {
                         wsteps++;
-                        if (walk_consume<STATS>(sc, wray, w, have, stack, cn, next, !last)) {
+                        if (walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
                             const uint32_t p = wpath;
                             sh.st[F_T][p] = __float_as_uint(w.rec.t);
                             sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
