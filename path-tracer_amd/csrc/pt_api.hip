@@ -712,28 +712,18 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     // variants' short cuts.  Measured on this GPU (tools/kernel_choice.py, 1080p, depth 8, pooled / per-tile, best of three
     // launches; profiles/r02/kernel_choice_scan_final.txt), one sample per frame: 2-12 frames 0.35-0.57 at every mesh
     // size; 16 frames 1.01-1.21; 32 frames 1.14-1.52; 96 frames 1.48-1.68; no triangles at all 0.95, Cornell (10
-    // triangles, 16 spp) 0.83.  Several samples per frame (round 1 and early round 2): 2 spp 0.89 at 3 k triangles, 0.95
-    // at 69 k, 0.96 at 10 M.
+    // triangles, 16 spp) 0.83.  2 to 16 samples per frame, 768 to 69 k triangles: 16 frames and more 1.32-1.57, 4 and 8
+    // frames 0.57-0.92 (profiles/r02/kernel_choice_scan_spp.txt).
     // Flags or PTRT_KERNEL force either; depth 0 and images wider or taller than 65535 always take the
     // per-tile kernel.
     const bool pool_possible = ctx->width <= 0xFFFFu && ctx->height <= 0xFFFFu && ctx->settings.depth >= 1u;
     const uint32_t launch_frames = ctx->window_size ? 1u : n_frames;  // a display window renders frame by frame
     // Several samples per pixel and frame (256 path slots per workgroup instead of 320, so that four workgroups
-    // still share a CU; work items sized by samples): a frame of n samples counts as n frames, but launches of 2 to
-    // 15 frames (one item per tile and frame) stay with the per-tile kernel.  Measured the same way, 2 to 16 spp:
-    // 48 samples or more per launch in 16 frames or more: 1.05-1.18 from 8.7k triangles on; 192 samples or more:
-    // 1.04-1.06 at 3k, 0.83-0.90 at 768; one frame of 64 or 256 samples: 1.08-1.17 from 8.7k on, 0.97-1.02 below;
-    // 4 frames of 16 samples: 0.69-0.94; 8 frames of 8: 0.88-1.02.
+    // still share a CU; work items sized by samples) follow the same rule; a single frame of many samples (its samples
+    // share one RNG stream per pixel and cannot be split) goes to the pooled kernel from 48 samples on big meshes.
     const uint32_t spp_now = std::max(ctx->settings.samples_per_pixel, 1u);
-    const uint64_t samples_now = (uint64_t)launch_frames * spp_now;
-    bool use_pool;
-    if (spp_now == 1u)
-        use_pool = ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES;
-    else
-        use_pool = (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES && samples_now >= PT_POOL_MULTI_MIN_SAMPLES &&
-                    (launch_frames == 1u || launch_frames >= PT_POOL_MULTI_MIN_FRAMES)) ||
-                   (ctx->n_tri_slots >= PT_POOL_MULTI_MIN_TRIANGLES_LONG && samples_now >= PT_POOL_MULTI_LONG_SAMPLES &&
-                    launch_frames >= PT_POOL_MULTI_MIN_FRAMES);
+    bool use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
+                    (launch_frames == 1u && spp_now >= PT_POOL_ONE_FRAME_MIN_SAMPLES && ctx->n_tri_slots >= PT_POOL_ONE_FRAME_MIN_TRIANGLES);
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = env_str("PTRT_KERNEL")) {  // "pool" / "tile": tuning builds only, overrides the flags

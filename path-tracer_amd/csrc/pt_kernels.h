@@ -19,21 +19,17 @@
 // summed by the host.
 #define PT_COUNTER_STRIPES 256u
 #define PT_COUNTER_PITCH 16u  // 64-bit words per stripe (one 128-byte line), >= PT_NUM_COUNTERS
-// At one sample per pixel and frame the pooled kernel takes launches of at least PT_POOL_MIN_FRAMES frames on meshes
-// of at least PT_POOL_MIN_TRIANGLES (pooled / per-tile, 1080p, depth 8, 192 to 69 k triangles: 16 frames 1.01-1.21,
-// 24 frames 1.01-1.38, 32 frames 1.14-1.52, 48 frames 1.31-1.53, 96 frames 1.48-1.68; 2 to 12 frames 0.35-0.57; no
-// triangles at all 0.95, ten triangles at 16 samples per frame 0.83).
+// The pooled kernel takes launches of at least PT_POOL_MIN_FRAMES frames on meshes of at least PT_POOL_MIN_TRIANGLES
+// (pooled / per-tile, 1080p, depth 8, 192 to 69 k triangles, one sample per frame: 16 frames 1.01-1.21, 24 frames
+// 1.01-1.38, 32 frames 1.14-1.52, 48 frames 1.31-1.53, 96 frames 1.48-1.68; 2 to 12 frames 0.35-0.57; no triangles at
+// all 0.95, ten triangles at 16 samples per frame 0.83; 2 to 16 samples per frame, 768 to 69 k triangles: 16 frames and
+// more 1.32-1.57, 4 and 8 frames 0.57-0.92), and single frames of at least PT_POOL_ONE_FRAME_MIN_SAMPLES samples on
+// meshes of at least PT_POOL_ONE_FRAME_MIN_TRIANGLES (one frame of 64 or 256 samples: 1.08-1.17 from 8.7 k triangles
+// on, 0.97-1.02 below).
 #define PT_POOL_MIN_TRIANGLES 128u
 #define PT_POOL_MIN_FRAMES 16u
-// With several samples per pixel and frame (no shading of sphere hits in the pass over misses, no sky-only tiles) the
-// rule counts samples per launch instead of frames: at least PT_POOL_MULTI_MIN_SAMPLES on meshes of at least
-// PT_POOL_MULTI_MIN_TRIANGLES, or PT_POOL_MULTI_LONG_SAMPLES on meshes of at least PT_POOL_MULTI_MIN_TRIANGLES_LONG,
-// in launches of one frame or (the second clause: only) of at least PT_POOL_MULTI_MIN_FRAMES.
-#define PT_POOL_MULTI_MIN_TRIANGLES 8192u
-#define PT_POOL_MULTI_MIN_SAMPLES 48u
-#define PT_POOL_MULTI_MIN_FRAMES 16u
-#define PT_POOL_MULTI_MIN_TRIANGLES_LONG 2048u
-#define PT_POOL_MULTI_LONG_SAMPLES 192u
+#define PT_POOL_ONE_FRAME_MIN_TRIANGLES 8192u
+#define PT_POOL_ONE_FRAME_MIN_SAMPLES 48u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
 // Launches of 2..15 frames plan one work item (a 1 KiB row of partial sums) per tile and frame so that the frames
 // run side by side; above this many bytes of such rows they run frame after frame instead (one item per tile, no

@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             v3 lcol = V3(1.0f, 1.0f, 1.0f), lidir = cur.d;
                             uint32_t lbounce = 0, llimit = 0;
                             if constexpr (GIZMO) llimit = L.depth;
-                            if constexpr (PT_INLINE_SPHERE_HITS && !STATS && SPP1) {
+                            if constexpr (PT_INLINE_SPHERE_HITS && !STATS) {
                                 if (!need_walk && nw.rec.hit) {
                                     PT_FRESH_PARAMS(LS);
                                     Ray br = cur;
