@@ -3,14 +3,15 @@
 // Device data layout (all hipMalloc, lives for the context):
 //   accum     width*height float4   running RGB sums, .w = frame count
 //   spheres   3 float4 per sphere   {center, radius} {albedo, material} {1/radius, 0, 0, 0}
-//   nodes     4 float4 per sibling  {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
-//             pair (l, l+1)         {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}: the pair interleaved
+//   walk table: one array of 64-byte records, everything a traversal step reads, addressed in 32-byte units
+//     sibling pair (l, l+1)         {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
+//                                   {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}: the pair interleaved
 //                                   component by component (two-wide slab tests), at the place of nodes l
 //                                   and l+1; the array is stored one node late so that every pair
 //                                   (odd, even index) is one 64-byte aligned block
-//   node_meta uint2 per node        (first, count), read only for leaves with > 7 triangles
-//   tri_pos   4 float4 per slot     {a, original index} {b-a} {c-a} {unused}, slot = position in the
-//                                   BVH's index permutation, so a leaf's triangles are contiguous
+//     triangle slot k               {a, original index} {b-a, material} {c-a, 0} {unused} behind the pairs, slot =
+//                                   position in the BVH's index permutation, so a leaf's triangles are contiguous
+//   node_meta uint2 per node        (table position of the first triangle, count), read only for leaves with > 7 triangles
 //   tri_nrm   3 float4 per slot     vertex normals, touched once per closest hit
 //   sky       6*size*size float4    cube faces +X,-X,+Y,-Y,+Z,-Z
 #include <algorithm>
@@ -50,8 +51,8 @@ struct pt_ctx {
 
     float4 *nodes_alloc = nullptr;
     uint2 *node_meta = nullptr;
-    float4 *tri_pos = nullptr, *tri_nrm = nullptr;
-    uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0;
+    float4 *tri_nrm = nullptr;
+    uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0, tri_base = 0;
     float4 root_pair[4] = {};
 
     float4 *sky = nullptr;
@@ -213,7 +214,6 @@ void free_mesh(pt_ctx *ctx)
 {
     dev_free(ctx->nodes_alloc);
     dev_free(ctx->node_meta);
-    dev_free(ctx->tri_pos);
     dev_free(ctx->tri_nrm);
     ctx->n_nodes = 0;
     ctx->n_tri_slots = 0;
@@ -232,7 +232,7 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.n_nodes = ctx->n_nodes;
     sc.root_token = ctx->root_token;
     for (int k = 0; k < 4; k++) sc.root_pair[k] = ctx->root_pair[k];
-    sc.tri_pos = ctx->tri_pos;
+    sc.tri_base = ctx->tri_base;
     sc.tri_nrm = ctx->tri_nrm;
     sc.sky = ctx->sky;
     sc.sky_size = ctx->sky_size;
@@ -458,7 +458,12 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
         return PT_OK;
     }
     if (!tris_v || !nodes_v || !tri_idx || n_tris == 0 || n_idx == 0) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: null or empty input with n_nodes=%u", n_nodes);
-    if (n_nodes >= (1u << 28) || n_idx >= (1u << 28)) return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: more than 2^28-1 nodes or indices");
+    // Walk table: node pairs (32 bytes per node, stored one node late) and, from the next 64-byte boundary on, one
+    // 64-byte record per triangle slot; positions are 32-byte units counted from the array's second unit.
+    const uint64_t tri_first_unit = ((uint64_t)n_nodes + 2) & ~1ull;  // even: 64-byte aligned
+    const uint64_t table_units = tri_first_unit + 2 * (uint64_t)n_idx;
+    if (table_units > (1ull << 27)) return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: %u nodes and %u triangle slots need a walk table of more than 4 GiB", n_nodes, n_idx);
+    const uint32_t tri_base = (uint32_t)tri_first_unit - 1u;
     const PtTriangle *tris = static_cast<const PtTriangle *>(tris_v);
     const PtNode *nodes = static_cast<const PtNode *>(nodes_v);
 
@@ -489,7 +494,7 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     auto token_of = [&](uint32_t i) -> uint32_t {
         const PtNode &n = nodes[i];
         if (n.triangle_count == 0) return n.left_child_index;
-        if (n.triangle_count <= 7u) return PT_TOKEN_LEAF | (n.triangle_count << 28) | n.left_child_index;
+        if (n.triangle_count <= 7u) return PT_TOKEN_LEAF | (n.triangle_count << 28) | (tri_base + 2u * n.left_child_index);
         return PT_TOKEN_LEAF | i;
     };
 
@@ -501,11 +506,11 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     // Sibling pairs (l, l+1), interleaved component by component so that the two slab tests of a node
     // visit are packed two-wide: {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
     // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}, at the place of nodes l and l+1.
-    std::vector<float4> h_nodes(2 * ((size_t)n_nodes + 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<float4> h_nodes(2 * (size_t)table_units, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     std::vector<uint2> h_meta(n_nodes);
     for (uint32_t i = 0; i < n_nodes; i++) {
         const PtNode &n = nodes[i];
-        h_meta[i] = make_uint2(n.left_child_index, n.triangle_count);
+        h_meta[i] = make_uint2(n.triangle_count ? tri_base + 2u * n.left_child_index : n.left_child_index, n.triangle_count);
         if (depth[i] < 0 || n.triangle_count != 0) continue;
         const PtNode &a = nodes[n.left_child_index], &b = nodes[n.left_child_index + 1];
         float4 *rec = &h_nodes[2 * ((size_t)n.left_child_index + 1)];
@@ -517,7 +522,8 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     // triangles as 64-byte records like the node pairs: a walk step reads one aligned record whichever it is, and a
     // random read of it is one 64-byte half line (48-byte records cost two of them three times in four)
     bool mesh_gizmo = false;
-    std::vector<float4> h_pos(4 * (size_t)n_idx, make_float4(0.0f, 0.0f, 0.0f, 0.0f)), h_nrm(3 * (size_t)n_idx);
+    float4 *const h_pos = h_nodes.data() + 2 * (size_t)tri_first_unit;
+    std::vector<float4> h_nrm(3 * (size_t)n_idx);
     for (uint32_t k = 0; k < n_idx; k++) {
         const PtTriangle &t = tris[tri_idx[k]];
         // edges as the shader computes them (compute.wgsl:353-354)
@@ -534,16 +540,16 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     free_mesh(ctx);
     int rc;
     if ((rc = dev_alloc(ctx, &ctx->nodes_alloc, h_nodes.size())) != PT_OK || (rc = dev_alloc(ctx, &ctx->node_meta, h_meta.size())) != PT_OK ||
-        (rc = dev_alloc(ctx, &ctx->tri_pos, h_pos.size())) != PT_OK || (rc = dev_alloc(ctx, &ctx->tri_nrm, h_nrm.size())) != PT_OK) {
+        (rc = dev_alloc(ctx, &ctx->tri_nrm, h_nrm.size())) != PT_OK) {
         free_mesh(ctx);
         return rc;
     }
     PT_HIP(ctx, hipMemcpy(ctx->nodes_alloc, h_nodes.data(), h_nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->node_meta, h_meta.data(), h_meta.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    PT_HIP(ctx, hipMemcpy(ctx->tri_pos, h_pos.data(), h_pos.size() * sizeof(float4), hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->tri_nrm, h_nrm.data(), h_nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
     ctx->n_nodes = n_nodes;
     ctx->n_tri_slots = n_idx;
+    ctx->tri_base = tri_base;
     ctx->mesh_has_gizmo = mesh_gizmo;
     ctx->root_token = token_of(0);
     if (nodes[0].triangle_count == 0)

@@ -52,15 +52,19 @@ struct PtDeviceScene {
     // spheres: 3 float4 each {center, radius} {albedo, material} {1/radius, 0, 0, 0}
     const float4 *spheres;
     uint32_t n_spheres;
-    // BVH: 4 float4 per sibling pair (l, l+1), interleaved {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
-    // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}; nodes + 2*l is the pair of the children l, l+1
+    // The walk table: one array of 64-byte records that a traversal step reads, addressed in 32-byte units from
+    // `nodes`.  Position l (odd) = the sibling pair (l, l+1), 4 float4 interleaved {lmin.x rmin.x lmin.y rmin.y}
+    // {lmin.z rmin.z lmax.x rmax.x} {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}; position tri_base + 2 k =
+    // the triangle in leaf-order slot k, {a, original index} {b-a, material} {c-a, 0} {unused}.  A leaf token's low
+    // bits are the position of its first triangle.  The whole table is under 4 GiB, so a position << 5 is a 32-bit
+    // byte offset.
     const float4 *nodes;
+    uint32_t tri_base;
     const uint2 *node_meta;  // (first, count) per node, read for big leaves only
     uint32_t n_nodes;
     uint32_t root_token;
     float4 root_pair[4];     // the root's two children (device node format), valid if the root is interior
-    // triangles in leaf order: 4 float4 each {a, original index} {b-a, material} {c-a, 0} {unused} / 3 float4 each {na} {nb} {nc}
-    const float4 *tri_pos;
+    // vertex normals in leaf order, 3 float4 per slot {na, albedo.r} {nb, albedo.g} {nc, albedo.b}: read once per closest hit
     const float4 *tri_nrm;
     // sky cube: 6 faces of sky_size^2 RGBA32F
     const float4 *sky;

@@ -60,7 +60,7 @@ struct Closest {
     bool hit;
     bool is_tri;
     float t;
-    uint32_t index;  // sphere index, or leaf-order triangle slot
+    uint32_t index;  // sphere index, or the walk-table position of the triangle's record
     float u, v;
 };
 
@@ -89,6 +89,14 @@ __device__ __forceinline__ void hit_aabb_pair(v3 o, v3 inv, float4 q0, float4 q1
     const float tmax_r = pt_min(pt_min(pt_max(t1x.y, t2x.y), pt_max(t1y.y, t2y.y)), pt_max(t1z.y, t2z.y));
     dl = (tmin_l > tmax_l || tmax_l < 0.0f) ? 99999.0f : tmin_l;
     dr = (tmin_r > tmax_r || tmax_r < 0.0f) ? 99999.0f : tmin_r;
+}
+
+// The 64-byte record at walk-table position `at` (a sibling pair or a triangle: one table, positions in 32-byte
+// units from sc.nodes).  The byte offset is a 32-bit value added to a wave-uniform base, so the load needs no
+// 64-bit vector arithmetic (pt_set_mesh keeps the table under 4 GiB).
+__device__ __forceinline__ const float4 *pt_walk_record(const PtDeviceScene &sc, uint32_t at)
+{
+    return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.nodes) + (size_t)(uint32_t)(at << 5));
 }
 
 // hitScene, compute.wgsl:214-302, split into "begin" (spheres in array order, traversal set-up)
@@ -214,7 +222,7 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     const uint32_t cur = w.node;
     if (!(cur & PT_TOKEN_LEAF)) {
         if (STATS) cn.interior++;
-        const float4 *pn = sc.nodes + 2 * (size_t)cur;  // children cur, cur+1: 64 contiguous bytes
+        const float4 *pn = pt_walk_record(sc, cur);  // children cur, cur+1: 64 contiguous bytes
         const float4 q0 = pn[0], q1 = pn[1], q2 = pn[2], q3 = pn[3];
         float d1, d2;
         hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
@@ -242,8 +250,8 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
     }
     // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
     for (uint32_t k = 0; k < count; k++) {
-        const uint32_t slot = first + k;
-        const float4 *tp = sc.tri_pos + 4 * (size_t)slot;
+        const uint32_t slot = first + 2u * k;  // (table position of the triangle's record)
+        const float4 *tp = pt_walk_record(sc, slot);
         const float4 A4 = tp[0], E1 = tp[1], E2 = tp[2];
         if (STATS) cn.tri_tests++;
         const v3 e1 = f4_xyz(E1), e2 = f4_xyz(E2);
@@ -280,8 +288,8 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
 // before any of them is used, so a wave whose lanes are at interior nodes and at leaves pays one
 // memory latency per step instead of one per kind.  Node and triangle order are unchanged.
 struct WalkU : Walk {
-    uint32_t leaf_next;  // next triangle slot of the leaf being tested
-    uint32_t leaf_left;  // triangles of that leaf still to test (0: w.node is still to be visited)
+    uint32_t leaf_left;  // triangles of the leaf being tested still to test; then w.node is the table position of the next
+                         // one's record (0: w.node is a token still to be visited)
 };
 
 // Call whenever w.node has been set: a leaf with an inline triangle count goes straight to
@@ -290,7 +298,7 @@ __device__ __forceinline__ void walk_enter(WalkU &w)
 {
     const uint32_t count = (w.node >> 28) & 7u;
     if ((w.node & PT_TOKEN_LEAF) && count != 0u) {
-        w.leaf_next = w.node & PT_TOKEN_LOW;
+        w.node &= PT_TOKEN_LOW;
         w.leaf_left = count;
     }
 }
@@ -304,11 +312,11 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
     if (!tri && (w.node & PT_TOKEN_LEAF)) {
         // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
         const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
-        w.leaf_next = m.x;
+        w.node = m.x;
         w.leaf_left = m.y;
         next_node = m.y == 0u;
     } else {
-        const float4 *base = tri ? sc.tri_pos + 4 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)w.node;
+        const float4 *base = pt_walk_record(sc, w.node);
         // all four loads for every lane (node pairs and triangles are both 64-byte records): issued together
         float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
@@ -333,8 +341,8 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             }
         } else {
             // hitTriangle, compute.wgsl:352-392 (edges precomputed: same subtraction)
-            const uint32_t slot = w.leaf_next;
-            w.leaf_next = slot + 1u;
+            const uint32_t slot = w.node;
+            w.node = slot + 2u;
             w.leaf_left--;
             next_node = w.leaf_left == 0u;
             if (STATS) cn.tri_tests++;
@@ -382,9 +390,9 @@ struct WalkQ {
 
 __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU &w, WalkQ &q)
 {
-    const bool tri = w.leaf_left != 0u;
-    const bool big = !tri && (w.node & PT_TOKEN_LEAF) != 0u;  // a big leaf is resolved through node_meta: nothing to fetch here
-    const float4 *base = tri ? sc.tri_pos + 4 * (size_t)w.leaf_next : sc.nodes + 2 * (size_t)(big ? 0u : w.node);
+    // (a big leaf's token, flag | node index, is resolved through node_meta and has nothing to fetch here: its flag bit
+    // leaves the 32-bit byte offset, so the loads read the node's own place in the table and are ignored)
+    const float4 *base = pt_walk_record(sc, w.node);
     q.q0 = base[0]; q.q1 = base[1]; q.q2 = base[2]; q.q3 = base[3];
 }
 
@@ -398,7 +406,7 @@ __device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, Walk
     if (!tri && (w.node & PT_TOKEN_LEAF)) {
         // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
         const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
-        w.leaf_next = m.x;
+        w.node = m.x;
         w.leaf_left = m.y;
         next_node = m.y == 0u;
     } else if (!tri) {
@@ -419,7 +427,7 @@ __device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, Walk
             if (d2 < w.nearest) stack.push(w.sp++, k2);
         }
     } else {
-        w.leaf_next++;
+        w.node += 2u;
         w.leaf_left--;
         next_node = w.leaf_left == 0u;
     }
@@ -466,7 +474,7 @@ template <bool STATS, typename StackT>
 __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
 {
     const bool tri = w.leaf_left != 0u;
-    const uint32_t slot = w.leaf_next;
+    const uint32_t slot = w.node;
     // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
     asm volatile("" : "+v"(q.q0.w), "+v"(q.q1.w), "+v"(q.q2.w), "+v"(q.q3.x), "+v"(q.q3.y));
     const bool over = walk_advance<STATS>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn);
@@ -521,7 +529,8 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
     h.p = v3_fma(c.t, ray.d, ray.o);
     v3 on;
     if (c.is_tri) {
-        const float4 *tn = sc.tri_nrm + 3 * (size_t)c.index;
+        const float4 *tp = pt_walk_record(sc, c.index);  // c.index: table position of the triangle's record
+        const float4 *tn = sc.tri_nrm + 3 * (size_t)((c.index - sc.tri_base) >> 1);
         const v3 an = f4_xyz(tn[0]), bn = f4_xyz(tn[1]), cnn = f4_xyz(tn[2]);
         const float w = (1.0f - c.u) - c.v;
         const v3 n = V3(pt_fma(cnn.x, c.v, pt_fma(bn.x, c.u, an.x * w)), pt_fma(cnn.y, c.v, pt_fma(bn.y, c.u, an.y * w)),
@@ -531,9 +540,9 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
         h.material = 0.0f;
         if (sc.tri_materials) {  // opt-in: the record's own albedo and material (model.rs:66-67)
             h.att = V3(tn[0].w, tn[1].w, tn[2].w);
-            h.material = sc.tri_pos[4 * (size_t)c.index + 1].w;
+            h.material = tp[1].w;
         }
-        h.prim = __float_as_uint(sc.tri_pos[4 * (size_t)c.index].w);
+        h.prim = __float_as_uint(tp[0].w);
     } else {
         const float4 s0 = sc.spheres[3 * c.index], s1 = sc.spheres[3 * c.index + 1];
         on = (h.p - f4_xyz(s0)) * sc.spheres[3 * c.index + 2].x;
@@ -706,7 +715,7 @@ __device__ __forceinline__ void pt_fresh_params(PtTraceParams &L)
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(PtTraceParams) / 4; i++) lw[i] = kw[i];  // unused words are never loaded
     pt_mark_constant(L.sc.spheres); pt_mark_global(L.sc.nodes); pt_mark_global(L.sc.node_meta);
-    pt_mark_global(L.sc.tri_pos); pt_mark_global(L.sc.tri_nrm); pt_mark_global(L.sc.sky);
+    pt_mark_global(L.sc.tri_nrm); pt_mark_global(L.sc.sky);
     pt_mark_global(L.items); pt_mark_global(L.partial); pt_mark_global(L.cost); pt_mark_global(L.accum);
     pt_mark_global(L.aov_prim); pt_mark_global(L.aov_t); pt_mark_global(L.counters); pt_mark_global(L.gstack);
     pt_mark_global(L.next_item);
@@ -849,7 +858,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     w.nearest = 9999.0f;
     w.node = 0;
     w.sp = 0;
-    w.leaf_next = w.leaf_left = 0;
+    w.leaf_left = 0;
 
     for (;;) {
         const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
         diag_steps++;
         {
             const unsigned long long wk = __ballot(mode == M_WALK);
-            const unsigned long long lf = __ballot(mode == M_WALK && (w.node & PT_TOKEN_LEAF));
+            const unsigned long long lf = __ballot(mode == M_WALK && (w.leaf_left != 0u || (w.node & PT_TOKEN_LEAF)));
             diag_c += ((unsigned long long)__popcll(wk) << 40) | ((unsigned long long)__popcll(lf) << 20) | (lf ? 1ull : 0ull);
         }
         if ((diag_steps & 1023u) == 0 && blockIdx.x < 64 && (diag_steps >> 10) <= 8 && lane == 0)
@@ -1320,7 +1329,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     w.nearest = 9999.0f;
     w.node = 0;
     w.sp = 0;
-    w.leaf_next = w.leaf_left = 0;
+    w.leaf_left = 0;
 
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
