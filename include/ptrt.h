@@ -90,7 +90,9 @@ int pt_set_flags(pt_ctx *ctx, uint32_t flags);
  * compute.wgsl:75-77).  Copied; the caller's memory is not referenced afterwards.  The BVH is
  * validated (child/leaf ranges in bounds, children stored after their parent) so that a
  * malformed tree is rejected instead of hanging the GPU; so is a tree deeper than 4096 levels
- * (PT_ERR_LIMIT: traversal stacks are sized by the depth).  n_nodes == 0 clears the mesh. */
+ * (PT_ERR_LIMIT: traversal stacks are sized by the depth), and a mesh whose device records (32 B
+ * per node + 64 B per index) would exceed 4 GiB, about 33 million triangles (PT_ERR_LIMIT: a
+ * traversal step addresses them with a 32-bit byte offset).  n_nodes == 0 clears the mesh. */
 int pt_set_mesh(pt_ctx *ctx, const void *tris, uint32_t n_tris, const void *nodes, uint32_t n_nodes,
                 const uint32_t *tri_idx, uint32_t n_idx);
 

@@ -321,7 +321,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         float4 q0 = base[0], q1 = base[1], q2 = base[2], q3 = base[3];
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
-        asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y));
+        asm volatile("" : : "v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.x), "v"(q3.y));
         if (!tri) {
             if (STATS) cn.interior++;
             float d1, d2;
@@ -476,7 +476,7 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d
     const bool tri = w.leaf_left != 0u;
     const uint32_t slot = w.node;
     // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
-    asm volatile("" : "+v"(q.q0.w), "+v"(q.q1.w), "+v"(q.q2.w), "+v"(q.q3.x), "+v"(q.q3.y));
+    asm volatile("" : : "v"(q.q0.w), "v"(q.q1.w), "v"(q.q2.w), "v"(q.q3.x), "v"(q.q3.y));
     const bool over = walk_advance<STATS>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn);
     if (prefetch && !over) walk_fetch(sc, w, qn);
     if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);

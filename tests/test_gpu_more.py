@@ -255,6 +255,91 @@ def test_degenerate_deep_tree_is_refused(pt, scenes):
     r.close()
 
 
+def _far_cluster(pt, origin, size, copies):
+    """`copies` identical triangles whose centroid lies beyond the middle of their box on every axis the builder can
+    pick: the partition leaves its left side empty and the node stays one leaf of `copies` triangles (bvh.rs:115-129)."""
+    t = np.zeros(1, pt.TRIANGLE_DTYPE)
+    o = np.asarray(origin, np.float32)
+    t["a"][0], t["b"][0], t["c"][0] = o, o + np.float32(size) * np.array([1, 0, 0], np.float32), o + np.float32(size) * np.array([1, 0.9, 0], np.float32)
+    t["na"][0] = t["nb"][0] = t["nc"][0] = (0, 0, 1)
+    t["albedo"][0] = (0.7, 0.6, 0.5)
+    return np.repeat(t, copies)
+
+
+def test_leaves_of_more_than_seven_triangles(pt, po, scenes):
+    """Leaves too big for a token's inline count (8 and more triangles) are resolved through the side table: primary-hit
+    ids (the first of the identical triangles in leaf order wins the tie), t, radiance and ray counts must be the
+    oracle's, in single dispatches and in a planned launch; also with such a leaf as the root."""
+    cam = pt.Camera.from_yaw_pitch((2.0, 0.4, 2.2), -90.0, 0.0)
+    st = pt.Settings(1, 5, 1e-4, 1000.0)
+    sky = scenes.sky_cube_direct(16)
+    meshes = {
+        "mixed": np.concatenate([_far_cluster(pt, (0.0, 0.0, 0.0), 0.8, 9), _far_cluster(pt, (1.2, 0.1, 0.2), 0.7, 20),
+                                 _far_cluster(pt, (2.4, 0.0, -0.3), 0.6, 7), _far_cluster(pt, (3.6, 0.2, 0.0), 0.5, 8)]),
+        "root": _far_cluster(pt, (1.5, 0.0, 0.0), 1.0, 12),
+    }
+    for name, tris in meshes.items():
+        scene = pt.Scene([pt.Sphere((2.0, -100.0, 0.0), 100.0, (0.5, 0.5, 0.5), pt.Material.Diffuse)], tris, cam)
+        counts = sorted(int(c) for c in scene.nodes["count"] if c)
+        assert counts == ([7, 8, 9, 20] if name == "mixed" else [12]), counts
+        w, h = 96, 64
+        r, osc = _pair(pt, po, scene, w, h, st, sky)
+        acc = np.zeros((h, w, 4), np.float32)
+        rays = 0
+        for t in (3, 4):
+            r.render(t)
+            acc, prim, tt, s = osc.render(t, acc, want_aov=True)
+            rays += s["rays"]
+        gprim, gt = r.read_aov()
+        assert np.array_equal(gprim, prim), (name, int((gprim != prim).sum()))
+        assert len(np.unique(prim[prim < 0x80000000])) == (4 if name == "mixed" else 1), "every cluster must be seen, one winner each"
+        _exact(gt, tt, name + ": primary t")
+        _exact(r.read_sum(), acc, name + ": radiance")
+        assert r.stats()["rays"] == rays
+        # a planned launch (the pooled kernel's walk in two halves when that kernel is chosen)
+        r.reset_ready_samples()
+        acc = np.zeros((h, w, 4), np.float32)
+        before = r.stats()["rays"]
+        rays = 0
+        for f in range(16):
+            acc, _, _, s = osc.render(20 + f, acc)
+            rays += s["rays"]
+        r.render_frames(20, 1, 16)
+        got = r.read_sum()
+        assert r.stats()["rays"] - before == rays
+        np.testing.assert_allclose(got, acc, rtol=16 * 2.0 ** -23, atol=1e-6)
+        # explicit rays through the plain (one record per step) walk of the query kernel
+        rng = np.random.RandomState(11)
+        o = (np.array([2.0, 0.4, 3.0], np.float32) + rng.uniform(-0.5, 0.5, (500, 3))).astype(np.float32)
+        d = (np.array([2.0, 0.3, 0.0], np.float32) + rng.uniform(-2, 2, (500, 3)) * np.array([1, 0.2, 0.1], np.float32) - o).astype(np.float32)
+        gp, gtt, _, gn, _ = r.trace_rays(o, d)
+        op, ott, _, on, _ = osc.trace_rays(o, d)
+        assert np.array_equal(gp, op)
+        hit = op != 0xFFFFFFFF
+        _exact(gtt[hit], ott[hit], name + ": query t")
+        _exact(gn[hit], on[hit], name + ": query normal")
+        r.close()
+
+
+def test_mesh_beyond_the_walk_table_limit_is_refused(pt, scenes):
+    """Node pairs and triangle records share one device array addressed with 32-bit byte offsets: counts that would
+    take it past 4 GiB are refused from the counts alone, before any array is read."""
+    cube = scenes.cornell()
+    r = pt.Renderer(scenes.three_balls(), 16, 16, settings=pt.Settings(1, 2, 1e-4, 1000.0))
+    tris = np.ascontiguousarray(cube.triangles, pt.TRIANGLE_DTYPE)
+    nodes = np.ascontiguousarray(cube.nodes, pt.NODE_DTYPE)
+    idx = np.ascontiguousarray(cube.triangle_indices, np.uint32)
+    ptr = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)
+    for n_nodes, n_idx in (((1 << 27) - 1, 4), (3, 1 << 26), (1 << 26, 1 << 25)):
+        rc = r._l.pt_set_mesh(r._ctx, ptr(tris), len(tris), ptr(nodes), n_nodes, ptr(idx), n_idx)
+        assert rc == -5, (n_nodes, n_idx, rc)  # PT_ERR_LIMIT
+        assert b"walk table" in r._l.pt_last_error(r._ctx)
+    r.set_mesh(tris, nodes, idx)  # the context is still usable
+    r.render(1)
+    assert r.stats()["rays"] > 0
+    r.close()
+
+
 def test_readouts(pt, scenes):
     scene = scenes.three_balls()
     r = pt.Renderer(scene, 64, 36, settings=pt.Settings(1, 4, 1e-4, 1000.0))
