@@ -147,8 +147,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # (PTRT_BENCH_FORCE_REDUCE=1: a one-rank process group, so that the reduce path can be rehearsed on a single GPU)
+    reduce_steps = world > 1 or os.environ.get("PTRT_BENCH_FORCE_REDUCE") == "1"
+    if reduce_steps:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pt = _pkgload.load()
     scenes = importlib.import_module("path_tracer_amd.scenes")
@@ -175,12 +182,12 @@ def main():
         r.render_frames(*frames_of_step(multi, rank, world, scaling, frames, i))
         if events:
             events[1].record(stream)
-        if world > 1:
-            multi.reduce_sum_to_root(accum, 0)
+        if reduce_steps:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # in place, on the launch stream's order (multi.reduce_sum_to_root)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if reduce_steps:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -200,7 +207,7 @@ def main():
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rr = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if reduce_steps:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
     elapsed_max, rays_total = float(tt.item()), float(rr.item())
@@ -261,7 +268,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if reduce_steps:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -368,7 +368,18 @@ static int pt_create_impl(int device, uint32_t width, uint32_t height, pt_ctx **
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sky, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_sky, 0, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
-    if (rc == PT_OK) step(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "side stream");
+    if (rc == PT_OK) {
+        // The side stream has to reach the GPU through another hardware queue than the launch stream, or its kernel
+        // runs behind the megakernel instead of beside it.  Streams of one priority share a small pool of queues
+        // (4 per process by default) in creation order, so in a process with several other streams -- RCCL's, a
+        // framework's -- a plain stream can land on the launch stream's queue; a stream of another priority draws
+        // from a pool of its own.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            step(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, greatest), "side stream");
+        else
+            step(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "side stream");
+    }
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) {
