@@ -70,8 +70,9 @@ struct pt_ctx {
     uint32_t *tile_cost = nullptr, *tile_sorted = nullptr, *next_item = nullptr;
     uint2 *tile_items = nullptr;
     uint32_t *tile_sky = nullptr;  // per tile: sees only the sky (PtSchedule::tile_sky)
-    hipStream_t side_stream = nullptr;  // the sky-only tiles' loop runs here, beside the megakernel
-    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    // planned launches with sky-only tiles: the megakernel on main_stream, the tiles' loop beside it on side_stream
+    hipStream_t main_stream = nullptr, side_stream = nullptr;
+    hipEvent_t fork_event = nullptr, start_event = nullptr, join_event = nullptr, main_event = nullptr;
     uint4 *items = nullptr;
     float4 *partial = nullptr;
     uint32_t item_cap = 0, n_tiles = 0, resident_waves = 5120;
@@ -368,20 +369,30 @@ static int pt_create_impl(int device, uint32_t width, uint32_t height, pt_ctx **
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sky, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_sky, 0, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
+    if (rc == PT_OK) step(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking), "main stream");
     if (rc == PT_OK) {
-        // The side stream has to reach the GPU through another hardware queue than the launch stream, or its kernel
-        // runs behind the megakernel instead of beside it.  Streams of one priority share a small pool of queues
-        // (4 per process by default) in creation order, so in a process with several other streams -- RCCL's, a
-        // framework's -- a plain stream can land on the launch stream's queue; a stream of another priority draws
-        // from a pool of its own.
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-            step(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, greatest), "side stream");
-        else
-            step(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "side stream");
+        // The side stream has to reach the GPU through another hardware queue than the main stream, or its kernel runs
+        // behind the megakernel instead of beside it.  A process's streams share a few queues (4 by default), handed
+        // out as streams come and go, so the pair is tested, and a stream that shares the main stream's queue is set
+        // aside (kept until the search is over, so that the next one created gets another queue) and the next one tried.
+        hipStream_t rejected[4];
+        int n_rejected = 0;
+        for (int attempt = 0; attempt < 4 && rc == PT_OK && !ctx->side_stream; attempt++) {
+            hipStream_t cand = nullptr;
+            step(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking), "side stream");
+            if (rc != PT_OK) break;
+            bool beside = false;
+            step(pt_streams_run_side_by_side(ctx->main_stream, cand, ctx->next_item + 8, &beside), "stream test");
+            if (rc == PT_OK && beside) ctx->side_stream = cand;
+            else rejected[n_rejected++] = cand;
+        }
+        for (int k = 0; k < n_rejected; k++) (void)hipStreamDestroy(rejected[k]);
+        // (no such stream found: the loop runs on the launch stream behind the megakernel, as without sky-only tiles)
     }
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming), "event");
+    if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming), "event");
+    if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->start_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -414,10 +425,13 @@ void pt_destroy(pt_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
-    if (ctx->side_stream) {
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
+    for (hipStream_t own : {ctx->main_stream, ctx->side_stream}) {
+        if (!own) continue;
+        (void)hipStreamSynchronize(own);
+        (void)hipStreamDestroy(own);
     }
+    if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
+    if (ctx->start_event) (void)hipEventDestroy(ctx->start_event);
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     dev_free(ctx->window_ring);
@@ -776,6 +790,9 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     sch.tile_sky = ctx->tile_sky;
     sch.sky_tiles = !env_str("PTRT_NO_SKY_TILES");  // (tuning builds: A/B switches)
     sch.side_stream = env_str("PTRT_NO_SIDE_STREAM") ? nullptr : ctx->side_stream;
+    sch.main_stream = ctx->main_stream;
+    sch.main_event = ctx->main_event;
+    sch.start_event = ctx->start_event;
     sch.fork_event = ctx->fork_event;
     sch.join_event = ctx->join_event;
     sch.cost_valid = &ctx->cost_valid;

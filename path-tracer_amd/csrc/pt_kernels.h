@@ -119,10 +119,11 @@ struct PtSchedule {
     uint2 *tile_items;     // n_tiles
     uint32_t *tile_sky;    // n_tiles: 1 for a tile whose camera rays all provably leave the scene (set when a launch is planned)
     bool sky_tiles;        // such tiles get no work items: their frames are summed by a loop of their own, frame after frame
-    // That loop waits on sky texels while the megakernel is bound by arithmetic, so it runs beside it on a stream
-    // of its own, forked from and joined back into the launch stream by these events (null: on the launch stream).
-    hipStream_t side_stream;
-    hipEvent_t fork_event, join_event;
+    // That loop waits on sky texels while the megakernel is bound by arithmetic, so it runs beside it: the megakernel
+    // on main_stream, the loop on side_stream -- two streams of the context's own, checked at creation to run side by
+    // side -- forked from and joined back into the launch stream by these events (null: all on the launch stream).
+    hipStream_t main_stream, side_stream;
+    hipEvent_t fork_event, start_event, join_event, main_event;
     uint4 *items;          // item_cap
     float4 *partial;       // item_cap * 64
     uint32_t item_cap;
@@ -163,6 +164,9 @@ struct PtRayQuery {
     uint32_t gstack_cap;
 };
 hipError_t pt_launch_ray_query(const PtRayQuery &q, uint32_t stack_depth, hipStream_t stream);
+// Runs a pair of tiny kernels (at most 0.5 ms each) to find out whether kernels of streams a and b run at the same
+// time, i.e. whether the two streams use different hardware queues.  dev_words: 4 device words of scratch.
+hipError_t pt_streams_run_side_by_side(hipStream_t a, hipStream_t b, uint32_t *dev_words, bool *result);
 size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth);
 
 // One finished frame into its slot of the rgba8unorm frame ring and onto the running sums; clears `frame`.

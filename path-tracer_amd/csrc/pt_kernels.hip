@@ -2486,6 +2486,8 @@ uint32_t pt_trace_item_cap(uint32_t n_tiles, uint32_t n_frames, const PtSchedule
     return (uint32_t)std::min<uint64_t>(std::max(uniform, planned), 0x7FFFFFFFull);
 }
 
+__global__ void delay_kernel(uint32_t ticks);
+
 hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_stats, const PtSchedule &sch, hipStream_t stream)
 {
     p.tiles_x = (p.width + PT_TILE - 1u) / PT_TILE;
@@ -2544,15 +2546,32 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     }
     p.items = sch.items;
     p.partial = sch.partial;
-    // The megakernel first (its workgroups take their places), then the sky loop into what is left of every CU.
-    const bool beside = sky_tiles && sch.side_stream && sch.fork_event && sch.join_event && p.cols != 0 && p.rows != 0;
-    if (beside && (e = hipEventRecord(sch.fork_event, stream)) != hipSuccess) return e;
-    e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, stream) : launch_items(p, cap, overflow, detailed_stats, stream);
+    // The megakernel first (its workgroups take their places), then the sky loop into what is left of every CU.  The two
+    // run on a pair of streams of the context's own that is known to reach the GPU through two hardware queues
+    // (pt_streams_run_side_by_side); the caller's stream only forks into them and joins them again.
+    const bool beside = sky_tiles && sch.main_stream && sch.side_stream && sch.fork_event && sch.start_event && sch.join_event && sch.main_event && p.cols != 0 && p.rows != 0;
+    const hipStream_t ms = beside ? sch.main_stream : stream;
+    // (the loop's stream waits for an event that the main stream records right before the megakernel, and then a few
+    // tens of microseconds more: released together with the megakernel -- two queues start within the same microsecond
+    // -- the loop's many small workgroups take places on the CUs that the megakernel's persistent groups then lack for
+    // the whole launch: 15.5-16.3 instead of 14.4 ms)
+    if (beside && ((e = hipEventRecord(sch.fork_event, stream)) != hipSuccess || (e = hipStreamWaitEvent(ms, sch.fork_event, 0)) != hipSuccess ||
+                   (e = hipEventRecord(sch.start_event, ms)) != hipSuccess)) return e;
+    e = pool ? launch_pool(p, cap, stack_depth, detailed_stats, sch, ms) : launch_items(p, cap, overflow, detailed_stats, ms);
+    if (beside) {  // (also after a failed launch: the caller's stream must not run ahead of what did get started)
+        hipError_t e2 = hipEventRecord(sch.main_event, ms);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(stream, sch.main_event, 0);
+        if (e == hipSuccess) e = e2;
+    }
     if (e != hipSuccess) return e;
     if (p.cols == 0 || p.rows == 0) return hipSuccess;  // image smaller than one 16x16 group under PT_FLAG_REFERENCE_DISPATCH: no pixel is rendered
     if (sky_tiles) {
         const hipStream_t ss = beside ? sch.side_stream : stream;
-        if (beside && (e = hipStreamWaitEvent(ss, sch.fork_event, 0)) != hipSuccess) return e;
+        if (beside) {
+            if ((e = hipStreamWaitEvent(ss, sch.start_event, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, ss, 3000u);  // 30 us
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         if (p.spp == 1u) hipLaunchKernelGGL(sky_tiles_kernel<true>, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
         else hipLaunchKernelGGL(sky_tiles_kernel<false>, dim3((p.n_tiles + 3u) / 4u), dim3(256), 0, ss, p, sch.tile_sky);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -2564,6 +2583,52 @@ hipError_t pt_launch_trace(PtTraceParams p, uint32_t stack_depth, bool detailed_
     hipLaunchKernelGGL(accumulate_kernel, dim3((p.cols + 63u) / 64u, (p.rows + 3u) / 4u), dim3(256), 0, stream, p.accum, p.partial,
                        sch.tile_items, p.width, p.tiles_x, p.cols, p.rows);
     return hipGetLastError();
+}
+
+// ---- do two streams reach the GPU through different hardware queues? -------------------------------
+// HIP multiplexes a process's streams onto a few hardware queues (4 by default), and kernels of two streams that share
+// one run one after the other.  Two one-thread kernels, one per stream, each raise a flag and wait -- for at most half a
+// millisecond -- for the other's: both see it only if they were on the GPU at the same time.  (On one queue the first
+// runs into its time limit before the second starts; the second then finds the first's flag, so BOTH must report.)
+// Holds its stream for `ticks` of the 100 MHz clock (bounded by the trip count as well).
+__global__ void delay_kernel(uint32_t ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t i = 0; i < 4096u; i++) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ void stream_probe_kernel(uint32_t *words, uint32_t mine)
+{
+    uint32_t *flag = words, *seen = words + 2;
+    __hip_atomic_store(&flag[mine], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    uint32_t ok = 0;
+    for (uint32_t i = 0; i < (1u << 16) && ok == 0u; i++) {  // (bounded twice: by the clock and by the trip count)
+        ok = __hip_atomic_load(&flag[mine ^ 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000ull) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    seen[mine] = ok;
+}
+
+hipError_t pt_streams_run_side_by_side(hipStream_t a, hipStream_t b, uint32_t *dev_words, bool *result)
+{
+    *result = false;
+    hipError_t e;
+    if ((e = hipMemsetAsync(dev_words, 0, 4 * sizeof(uint32_t), a)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(1), 0, a, dev_words, 0u);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(1), 0, b, dev_words, 1u);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(a)) != hipSuccess || (e = hipStreamSynchronize(b)) != hipSuccess) return e;
+    uint32_t h[4] = {0, 0, 0, 0};
+    if ((e = hipMemcpy(h, dev_words, sizeof(h), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    *result = h[2] != 0u && h[3] != 0u;
+    return hipSuccess;
 }
 
 size_t pt_ray_query_gstack_bytes(uint32_t n, uint32_t stack_depth)
