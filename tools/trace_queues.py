@@ -12,6 +12,6 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("pool_kernel", "trace_kernel", "sky_tiles", "accumulate", "probe"))]
 t0 = int(keep[0]["Start_Timestamp"]) if keep else 0
 for r in keep[-16:]:
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+    name = next(k for k in ("pool_kernel", "trace_kernel", "sky_tiles_kernel", "accumulate_kernel", "stream_probe_kernel", "sky_tiles", "accumulate", "probe") if k in r["Kernel_Name"])
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f"queue {r.get('Queue_Id', '?'):>3}  start {(s - t0) / 1e6:10.3f} ms  dur {(e - s) / 1e6:8.3f} ms  {name}")
