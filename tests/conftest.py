@@ -13,13 +13,15 @@ import _pkgload  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "library_choice: a GPU test that runs once, with the library's own kernel choice")
 
 
 def pytest_generate_tests(metafunc):
     """Every GPU test runs twice: once with the pooled megakernel forced, once with the per-tile one
     (the library itself picks by mesh size, which would leave one of them untested on small scenes)."""
     own = hasattr(metafunc.module, "megakernel")  # a module that picks kernels itself overrides the fixture
-    if metafunc.definition.get_closest_marker("gpu") is not None and "megakernel" in metafunc.fixturenames and not own:
+    once = metafunc.definition.get_closest_marker("library_choice") is not None
+    if metafunc.definition.get_closest_marker("gpu") is not None and "megakernel" in metafunc.fixturenames and not own and not once:
         metafunc.parametrize("megakernel", ["pool", "tile"], indirect=True)
 
 

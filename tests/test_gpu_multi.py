@@ -43,3 +43,27 @@ def test_two_hip_ranks_sum_to_the_single_rank_image(pt, po, scenes, tmp_path, me
         orays += s["rays"]
     assert rays == orays
     np.testing.assert_allclose(got["sum"], want, rtol=frames * 2.0 ** -23, atol=1e-6)
+
+
+@pytest.mark.library_choice
+def test_bench_step_with_the_reduce_path_on_one_rank(tmp_path):
+    """bench.py's N > 1 step -- RCCL group, sum-reduce of the device sums, barrier, all-reduces of time and rays -- run
+    on this one GPU as a one-rank group (PTRT_BENCH_FORCE_REDUCE=1), beside the plain one-process run of the same
+    steps: same rays, a well-formed line, and a step that is not slower for having RCCL's streams in the process (the
+    sky-only tiles' loop must still run beside the megakernel; 1.08 x when it does not)."""
+    import json
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "3", "--no-cpu-baseline"]
+    lines = []
+    for forced in (False, True):
+        env = dict(os.environ)
+        env.pop("PTRT_KERNEL", None)
+        if forced:
+            env["PTRT_BENCH_FORCE_REDUCE"] = "1"
+        out = subprocess.run(args, env=env, capture_output=True, text=True, timeout=110)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    plain, forced = lines
+    for d in lines:
+        assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "Mrays/s" and d["roofline"]["kernel_ms"] > 0
+    assert forced["config"]["rays_per_step"] == plain["config"]["rays_per_step"]
+    assert forced["ms_per_step"] < 1.05 * plain["ms_per_step"], (forced["ms_per_step"], plain["ms_per_step"])
