@@ -18,6 +18,10 @@
  * context (or, with NULL, of the last failed pt_create on this thread).  A context is
  * bound to one GPU and must be used from one host thread at a time.  Calls that launch
  * work are asynchronous on the context's stream unless they return data to the host.
+ * Launches of two frames and more may run part of their kernels on two streams that the
+ * context creates for itself (pt_create also runs two half-millisecond-bounded test kernels
+ * on them); those streams are forked from and joined back into the context's stream inside
+ * the call, so ordering on the context's stream is all a caller has to think about.
  */
 #ifndef PTRT_H
 #define PTRT_H
