@@ -290,6 +290,8 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
 struct WalkU : Walk {
     uint32_t leaf_left;  // triangles of the leaf being tested still to test; then w.node is the table position of the next
                          // one's record (0: w.node is a token still to be visited)
+    uint32_t top;        // walks that keep the newest stack entry in a register (walk_advance<.., true>): that entry,
+                         // valid while sp != 0; entries 0 .. sp-2 are in the stack's memory
 };
 
 // Call whenever w.node has been set: a leaf with an inline triangle count goes straight to
@@ -398,8 +400,15 @@ __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU 
 
 // First half of a step on the loaded record q: moves the walk to where it goes next.  Returns true when the walk is
 // over.  (A lane at a triangle only counts it off here; walk_triangle tests it.)
-template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, WalkU &w, float4 q0, float4 q1, float4 q2, float4 q3, StackT stack, Counters &cn)
+// TOP_CACHED: the newest stack entry lives in w.top.  A push stores the entry it displaces, a pop loads the entry that
+// becomes the newest -- a value that nothing needs before the walk's next push or pop, a whole record fetch later, so
+// the step never waits for its own stack read; and a push onto an empty stack or a pop of the only entry (most of them:
+// walks are shallow) touches no memory at all.
+// (The loaded entry is handed back in `below`, with `popped` set, for the caller to move into w.top AFTER the rest of
+// the step: assigned here, inside the branch, the move would sit at the branch's end and wait for the read there.)
+template <bool STATS, bool TOP_CACHED = false, typename StackT>
+__device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, WalkU &w, float4 q0, float4 q1, float4 q2, float4 q3, StackT stack, Counters &cn,
+                                             uint32_t *below = nullptr, bool *popped = nullptr)
 {
     const bool tri = w.leaf_left != 0u;
     bool next_node = false;
@@ -424,7 +433,15 @@ __device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, Walk
             next_node = true;
         } else {
             w.node = k1;
-            if (d2 < w.nearest) stack.push(w.sp++, k2);
+            if (d2 < w.nearest) {
+                if constexpr (TOP_CACHED) {
+                    if (w.sp != 0u) stack.push(w.sp - 1u, w.top);
+                    w.top = k2;
+                    w.sp++;
+                } else {
+                    stack.push(w.sp++, k2);
+                }
+            }
         }
     } else {
         w.node += 2u;
@@ -433,8 +450,16 @@ __device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, Walk
     }
     bool over = false;
     if (next_node) {
-        if (w.sp == 0) over = true;
-        else w.node = stack.pop(--w.sp);
+        if (w.sp == 0) {
+            over = true;
+        } else if constexpr (TOP_CACHED) {
+            w.node = w.top;
+            w.sp--;
+            // (of an empty stack: some value, never used; an entry beyond the LDS part is rare and goes to w.top at once)
+            *popped = stack.peek_newest(w.sp, *below, w.top);
+        } else {
+            w.node = stack.pop(--w.sp);
+        }
     }
     if (!over && (!tri || next_node)) walk_enter(w);
     return over;
@@ -470,16 +495,24 @@ __device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 
 }
 
 // A whole step: advance, the next record's loads (`prefetch` is wave-uniform), triangle test.  True when the walk is over.
-template <bool STATS, typename StackT>
+template <bool STATS, bool TOP_CACHED = false, typename StackT>
 __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
 {
     const bool tri = w.leaf_left != 0u;
     const uint32_t slot = w.node;
     // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
     asm volatile("" : : "v"(q.q0.w), "v"(q.q1.w), "v"(q.q2.w), "v"(q.q3.x), "v"(q.q3.y));
-    const bool over = walk_advance<STATS>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn);
+    uint32_t below = 0;
+    bool popped = false;
+    const bool over = walk_advance<STATS, TOP_CACHED>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn, &below, &popped);
     if (prefetch && !over) walk_fetch(sc, w, qn);
     if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
+    if constexpr (TOP_CACHED) {
+        // (here, not at the pop: the stack read has had the triangle test's time to arrive; the empty asm pins the
+        // value's first use to this place, or the compiler folds the move back into the pop's branch)
+        asm volatile("" : "+v"(below));
+        if (popped) w.top = below;
+    }
     return over;
 }
 
@@ -859,6 +892,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     w.node = 0;
     w.sp = 0;
     w.leaf_left = 0;
+    w.top = 0;
 
     for (;;) {
         const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
@@ -1097,6 +1131,20 @@ struct PPStack {
         if (sp >= PT_PP_STACK) v = spill[(size_t)(sp - PT_PP_STACK) * pitch];
         return v;
     }
+    // The same read for a value that is not needed at once: nothing here makes the caller wait for the LDS read
+    // (the statement that keeps the two reads apart sits in the rare branch).
+    // Entry n - 1 of a stack of n entries, for a caller that needs it later: an entry of the LDS part is read into
+    // `later` (true is returned; of an empty stack: whatever the last LDS entry holds -- no branch, no fault), so that
+    // nothing but that LDS read stands between the caller and the value; an entry of the spilled part is loaded into
+    // `now` on the spot (false).
+    __device__ __forceinline__ bool peek_newest(uint32_t n, uint32_t &later, uint32_t &now)
+    {
+        const uint32_t e = n - 1u;
+        later = lds[min(e, (uint32_t)PT_PP_STACK - 1u) * PT_PP_THREADS];
+        const bool deep = (int32_t)e >= (int32_t)PT_PP_STACK;
+        if (deep) now = spill[(size_t)(e - PT_PP_STACK) * pitch];
+        return !deep;
+    }
 };
 
 // Self-checks of the pooled kernel.  None of them is expected to fire; each costs a compare on a path that is taken
@@ -1330,6 +1378,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     w.node = 0;
     w.sp = 0;
     w.leaf_left = 0;
+    w.top = 0;
 
 #ifdef PT_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1397,7 +1446,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 w.leaf_left = 0;
                 walk_enter(w);
                 const uint32_t k2 = sh.st[F_V][p];
+#if PT_POOL_PIPELINED_WALK
+                if (k2 != 0xFFFFFFFFu) { w.top = k2; w.sp = 1u; }  // (the newest stack entry stays in a register)
+#else
                 if (k2 != 0xFFFFFFFFu) stack.push(w.sp++, k2);
+#endif
                 wsteps = 0;
                 wbusy = true;
             }
@@ -1440,7 +1493,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                     if (wbusy) {
                         wsteps++;
-                        if (walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
+                        if (walk_consume<STATS, true>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
                             const uint32_t p = wpath;
                             sh.st[F_T][p] = __float_as_uint(w.rec.t);
                             sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
