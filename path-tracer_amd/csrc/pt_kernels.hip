@@ -290,8 +290,8 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
 struct WalkU : Walk {
     uint32_t leaf_left;  // triangles of the leaf being tested still to test; then w.node is the table position of the next
                          // one's record (0: w.node is a token still to be visited)
-    uint32_t top;        // walks that keep the newest stack entry in a register (walk_advance<.., true>): that entry,
-                         // valid while sp != 0; entries 0 .. sp-2 are in the stack's memory
+    uint32_t top;        // walks that keep the newest stack entry in a register (walk_consume): that entry, valid while
+                         // sp != 0; entries 0 .. sp-2 are in the stack's memory
 };
 
 // Call whenever w.node has been set: a leaf with an inline triangle count goes straight to
@@ -398,73 +398,6 @@ __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU 
     q.q0 = base[0]; q.q1 = base[1]; q.q2 = base[2]; q.q3 = base[3];
 }
 
-// First half of a step on the loaded record q: moves the walk to where it goes next.  Returns true when the walk is
-// over.  (A lane at a triangle only counts it off here; walk_triangle tests it.)
-// TOP_CACHED: the newest stack entry lives in w.top.  A push stores the entry it displaces, a pop loads the entry that
-// becomes the newest -- a value that nothing needs before the walk's next push or pop, a whole record fetch later, so
-// the step never waits for its own stack read; and a push onto an empty stack or a pop of the only entry (most of them:
-// walks are shallow) touches no memory at all.
-// (The loaded entry is handed back in `below`, with `popped` set, for the caller to move into w.top AFTER the rest of
-// the step: assigned here, inside the branch, the move would sit at the branch's end and wait for the read there.)
-template <bool STATS, bool TOP_CACHED = false, typename StackT>
-__device__ __forceinline__ bool walk_advance(const PtDeviceScene &sc, v3 o, WalkU &w, float4 q0, float4 q1, float4 q2, float4 q3, StackT stack, Counters &cn,
-                                             uint32_t *below = nullptr, bool *popped = nullptr)
-{
-    const bool tri = w.leaf_left != 0u;
-    bool next_node = false;
-    if (!tri && (w.node & PT_TOKEN_LEAF)) {
-        // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
-        const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
-        w.node = m.x;
-        w.leaf_left = m.y;
-        next_node = m.y == 0u;
-    } else if (!tri) {
-        if (STATS) cn.interior++;
-        float d1, d2;
-        hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
-        uint32_t k1 = __float_as_uint(q3.x), k2 = __float_as_uint(q3.y);
-        {  // near child first (selects: cheaper than a lane mask around four moves)
-            const bool far_first = d1 > d2;
-            const float n = far_first ? d2 : d1, f = far_first ? d1 : d2;
-            const uint32_t kn = far_first ? k2 : k1, kf = far_first ? k1 : k2;
-            d1 = n; d2 = f; k1 = kn; k2 = kf;
-        }
-        if (d1 > w.nearest) {
-            next_node = true;
-        } else {
-            w.node = k1;
-            if (d2 < w.nearest) {
-                if constexpr (TOP_CACHED) {
-                    if (w.sp != 0u) stack.push(w.sp - 1u, w.top);
-                    w.top = k2;
-                    w.sp++;
-                } else {
-                    stack.push(w.sp++, k2);
-                }
-            }
-        }
-    } else {
-        w.node += 2u;
-        w.leaf_left--;
-        next_node = w.leaf_left == 0u;
-    }
-    bool over = false;
-    if (next_node) {
-        if (w.sp == 0) {
-            over = true;
-        } else if constexpr (TOP_CACHED) {
-            w.node = w.top;
-            w.sp--;
-            // (of an empty stack: some value, never used; an entry beyond the LDS part is rare and goes to w.top at once)
-            *popped = stack.peek_newest(w.sp, *below, w.top);
-        } else {
-            w.node = stack.pop(--w.sp);
-        }
-    }
-    if (!over && (!tri || next_node)) walk_enter(w);
-    return over;
-}
-
 // Second half, for a lane that stood at triangle `slot` with its record in q: hitTriangle, compute.wgsl:352-392 (edges
 // precomputed: same subtraction), straight-line as in walk_step_u.
 template <bool STATS>
@@ -494,25 +427,77 @@ __device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 
     }
 }
 
-// A whole step: advance, the next record's loads (`prefetch` is wave-uniform), triangle test.  True when the walk is over.
-template <bool STATS, bool TOP_CACHED = false, typename StackT>
+// A whole step on the loaded record q (the record w.node points at), in the order that keeps the walk's chain of
+// dependent fetches short: (1) where the walk goes next -- an interior lane from its two box tests, a lane at a triangle
+// from the leaf's count, either of them possibly from the stack -- as one token; (2) the next record's loads, straight
+// from that token (`prefetch` is wave-uniform); (3) everything no address depends on: the stack's bookkeeping, entering
+// the node, the triangle test.  True when the walk is over.
+// The newest stack entry lives in w.top.  A push stores the entry it displaces, a pop takes w.top and loads the entry
+// that becomes the newest -- a value that nothing needs before the walk's next push or pop, a whole record fetch later:
+// the read goes into `below` and is moved into w.top at the very end of the step, so no step waits for its own stack
+// read.  A push onto an empty stack and a pop of the only entry (most of them: walks are shallow) touch no memory.
+template <bool STATS, typename StackT>
 __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
 {
     const bool tri = w.leaf_left != 0u;
     const uint32_t slot = w.node;
     // (the empty asm uses the loaded values here, so that the compiler waits for them once, before the branches)
     asm volatile("" : : "v"(q.q0.w), "v"(q.q1.w), "v"(q.q2.w), "v"(q.q3.x), "v"(q.q3.y));
-    uint32_t below = 0;
-    bool popped = false;
-    const bool over = walk_advance<STATS, TOP_CACHED>(sc, o, w, q.q0, q.q1, q.q2, q.q3, stack, cn, &below, &popped);
-    if (prefetch && !over) walk_fetch(sc, w, qn);
-    if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
-    if constexpr (TOP_CACHED) {
-        // (here, not at the pop: the stack read has had the triangle test's time to arrive; the empty asm pins the
-        // value's first use to this place, or the compiler folds the move back into the pop's branch)
-        asm volatile("" : "+v"(below));
-        if (popped) w.top = below;
+    // (1)
+    uint32_t next = slot + 2u;         // a lane at a triangle: the leaf's next triangle ...
+    bool leave = w.leaf_left == 1u;    // ... unless this was the last one: the next node comes off the stack
+    bool push = false;
+    uint32_t far_child = 0;
+    if (!tri) {
+        if (w.node & PT_TOKEN_LEAF) {
+            // big leaf: (first, count) from the side table (rare: the builder splits down to two triangles)
+            const uint2 m = sc.node_meta[w.node & PT_TOKEN_LOW];
+            next = m.x;
+            w.leaf_left = m.y;
+            leave = m.y == 0u;
+        } else {
+            if (STATS) cn.interior++;
+            float d1, d2;
+            hit_aabb_pair(o, w.inv, q.q0, q.q1, q.q2, d1, d2);
+            const uint32_t kl = __float_as_uint(q.q3.x), kr = __float_as_uint(q.q3.y);
+            // near child first (selects: cheaper than a lane mask around four moves)
+            const bool far_first = d1 > d2;
+            const float dn = far_first ? d2 : d1, df = far_first ? d1 : d2;
+            next = far_first ? kr : kl;
+            far_child = far_first ? kl : kr;
+            leave = dn > w.nearest;
+            push = !leave && df < w.nearest;
+        }
     }
+    const bool over = leave && w.sp == 0u, pops = leave && w.sp != 0u;
+    if (pops) next = w.top;
+    // (2) (a token's flag and count bits leave the 32-bit byte offset: a leaf's token addresses its first triangle, and
+    // a big leaf's, flag | node index, the node's own place in the table -- loads that are ignored)
+    if (prefetch && !over) {
+        const float4 *base = pt_walk_record(sc, next);
+        qn.q0 = base[0]; qn.q1 = base[1]; qn.q2 = base[2]; qn.q3 = base[3];
+    }
+    // (3)
+    if (push) {
+        if (w.sp != 0u) stack.push(w.sp - 1u, w.top);
+        w.top = far_child;
+        w.sp++;
+    }
+    uint32_t below = 0;
+    bool below_is_top = false;
+    if (pops) {
+        w.sp--;
+        // (of an empty stack: some value, never used; an entry beyond the LDS part is rare and goes to w.top at once)
+        below_is_top = stack.peek_newest(w.sp, below, w.top);
+    }
+    if (tri) w.leaf_left--;
+    w.node = next;
+    if (!over && (!tri || leave)) walk_enter(w);
+    if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
+    // (the empty asm pins the stack read's first use to this place, or the compiler folds the move back into the pop's
+    // branch and waits there)
+    asm volatile("" : "+v"(below));
+    if (below_is_top) w.top = below;
     return over;
 }
 
@@ -1493,7 +1478,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                     if (wbusy) {
                         wsteps++;
-                        if (walk_consume<STATS, true>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
+                        if (walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
                             const uint32_t p = wpath;
                             sh.st[F_T][p] = __float_as_uint(w.rec.t);
                             sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
