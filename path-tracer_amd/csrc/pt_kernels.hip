@@ -1038,6 +1038,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
 #ifndef PT_PP_WAVES_PER_EU
 #define PT_PP_WAVES_PER_EU 4
 #endif
+#define PT_PP_ITEM_BATCH 4u  // work items claimed per trip to the launch's item counter
 static_assert(PT_PP_PATHS % PT_PP_WAVES == 0 && PT_PP_PATHS <= PT_PP_QCAP && (PT_PP_QCAP & (PT_PP_QCAP - 1)) == 0, "pool geometry");
 static_assert(PT_PP_PATHS_WIDE % PT_PP_WAVES == 0 && PT_PP_PATHS_WIDE <= PT_PP_PATHS, "pool geometry");
 
@@ -1089,6 +1090,11 @@ struct PPShared {
     uint32_t no_more;            // the launch's item counter is exhausted
     uint32_t group;              // the workgroup's index, parked here for the end of the kernel
     pp_u32x4 item;               // x0 | y0 << 16, first frame, end frame, item index (read after an acquire fence)
+    // Work items fetched ahead: the launch's item counter and the item table are global memory, two dependent round
+    // trips that the group would otherwise pay every 64 pixels; they are paid once per PT_PP_ITEM_BATCH items (records
+    // loaded side by side) and the others are opened from here.  Touched only by the holder of job_lock.
+    uint32_t staged[PT_PP_ITEM_BATCH][4];  // {tile, first frame, frames, item index}
+    uint32_t staged_pos;                   // next entry to open (PT_PP_ITEM_BATCH: none left)
 };
 
 // Hand-shake words are accessed with relaxed workgroup-scope atomics (plain ds_read/ds_write that the
@@ -1254,6 +1260,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
         sh.job_word = 64u;
         sh.job_lock = 0;
         sh.no_more = 0;
+        sh.staged_pos = PT_PP_ITEM_BATCH;
         sh.group = blockIdx.x;
     }
     __syncthreads();
@@ -1291,11 +1298,37 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         // still handed out completely, and nobody else is replacing it: open the next item
                         uint32_t it = 0, tile = 0, f0 = 0, fc = 0;
                         bool have = false;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (the staged items were written by an earlier holder of the lock)
                         for (;;) {
-                            it = atomicAdd(L.next_item, 1u);
-                            if (it >= L.n_items) break;
-                            if (DIRECT) { tile = it; f0 = 0; fc = L.n_frames; }
-                            else { const uint4 rec = L.items[it]; tile = rec.x; f0 = rec.y; fc = rec.z; }
+                            uint32_t pos = lds_load(&sh.staged_pos);
+                            if (pos >= PT_PP_ITEM_BATCH) {
+                                // one trip to the launch's counter for a batch of items; their records are loaded side by side
+                                const uint32_t base = atomicAdd(L.next_item, (uint32_t)PT_PP_ITEM_BATCH);
+                                uint4 recs[PT_PP_ITEM_BATCH];
+#pragma unroll
+                                for (uint32_t k = 0; k < PT_PP_ITEM_BATCH; k++) {
+                                    const uint32_t i = base + k;
+                                    recs[k] = make_uint4(0u, 0u, 0u, 0u);
+                                    if (i < L.n_items) {
+                                        if (DIRECT) recs[k] = make_uint4(i, 0u, L.n_frames, 0u);
+                                        else recs[k] = L.items[i];
+                                    }
+                                }
+#pragma unroll
+                                for (uint32_t k = 0; k < PT_PP_ITEM_BATCH; k++) {
+                                    lds_store(&sh.staged[k][0], recs[k].x);
+                                    lds_store(&sh.staged[k][1], recs[k].y);
+                                    lds_store(&sh.staged[k][2], recs[k].z);
+                                    lds_store(&sh.staged[k][3], base + k);
+                                }
+                                pos = 0;
+                            }
+                            tile = lds_load(&sh.staged[pos][0]);
+                            f0 = lds_load(&sh.staged[pos][1]);
+                            fc = lds_load(&sh.staged[pos][2]);
+                            it = lds_load(&sh.staged[pos][3]);
+                            lds_store(&sh.staged_pos, pos + 1u);
+                            if (it >= L.n_items) break;            // (items are claimed in rising order: none left)
                             if (fc != 0u) { have = true; break; }  // zero frames: an unused entry of the item table
                         }
                         if (!have) {
