@@ -755,6 +755,11 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     const uint32_t spp_now = std::max(ctx->settings.samples_per_pixel, 1u);
     bool use_pool = (ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES && launch_frames >= PT_POOL_MIN_FRAMES) ||
                     (launch_frames == 1u && spp_now >= PT_POOL_ONE_FRAME_MIN_SAMPLES && ctx->n_tri_slots >= PT_POOL_ONE_FRAME_MIN_TRIANGLES);
+    // Short launches at one sample per frame (one work item per tile and frame): since work items are claimed in
+    // batches they are the pooled kernel's, too, from 8 frames on meshes of 512 triangles and more, from 4 on big ones.
+    if (spp_now == 1u && ((launch_frames >= PT_POOL_SHORT_MIN_FRAMES && ctx->n_tri_slots >= PT_POOL_SHORT_MIN_TRIANGLES) ||
+                          (launch_frames >= PT_POOL_SHORT_BIG_MIN_FRAMES && ctx->n_tri_slots >= PT_POOL_SHORT_BIG_MIN_TRIANGLES)))
+        use_pool = true;
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = env_str("PTRT_KERNEL")) {  // "pool" / "tile": tuning builds only, overrides the flags
@@ -811,7 +816,9 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     sch.wanted_items = env_u32("PTRT_WANTED_ITEMS", ctx->resident_waves * per_slot);
     sch.default_chunk = 32;
     sch.max_chunk = env_u32("PTRT_MAX_CHUNK", 0);
-    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? (spp == 1u ? 2u : std::max(4u / spp, 1u)) : 1);
+    // (the shortest planned launches, 16 to 23 frames, are bound by their costliest tiles' chains of frames: single-frame
+    // items there, 1.96 -> 1.76 ms at 16 frames; from 24 frames on items of at least two frames are as good or better)
+    sch.min_chunk = env_u32("PTRT_MIN_CHUNK", use_pool ? (spp == 1u ? (launch_frames < 24u ? 1u : 2u) : std::max(4u / spp, 1u)) : 1);
     // Launches of 2..15 frames: one work item per tile AND frame, the items' single-frame sums added in frame order,
     // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
     // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).

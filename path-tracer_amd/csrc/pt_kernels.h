@@ -28,6 +28,14 @@
 // on, 0.97-1.02 below).
 #define PT_POOL_MIN_TRIANGLES 128u
 #define PT_POOL_MIN_FRAMES 16u
+// Launches of 2 to 15 frames at one sample per frame (one work item per tile and frame, sums exactly those of separate
+// dispatches), pooled / per-tile time, 1080p, depth 8: 192 triangles 1.25 / 1.14 / 1.07 / 0.97 / 0.97 at 2 / 4 / 8 / 12 / 15
+// frames; 768: 1.19 / 1.05 / 0.96 / 0.86 / 0.85; 3 k: 1.12 / 1.02 / 0.93 / 0.85 / 0.82; 12 k: 1.08 / 0.96 / 0.89 / 0.82 / 0.79;
+// 69 k: 1.02 / 0.90 / 0.81 / 0.72 / 0.71.
+#define PT_POOL_SHORT_MIN_FRAMES 8u
+#define PT_POOL_SHORT_MIN_TRIANGLES 512u
+#define PT_POOL_SHORT_BIG_MIN_FRAMES 4u
+#define PT_POOL_SHORT_BIG_MIN_TRIANGLES 8192u
 #define PT_POOL_ONE_FRAME_MIN_TRIANGLES 8192u
 #define PT_POOL_ONE_FRAME_MIN_SAMPLES 48u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
