@@ -277,7 +277,7 @@ def r_uses_pool(pt, scene, settings, frames_per_launch: int) -> bool:
     """Mirror of the library's kernel choice (pt_kernels.h: PT_POOL_*), for the roofline block's label only."""
     tris, spp = len(scene.triangles), max(settings.samples_per_pixel, 1)
     return ((tris >= 128 and frames_per_launch >= 16) or (frames_per_launch == 1 and spp >= 48 and tris >= 8192)
-            or (spp == 1 and ((frames_per_launch >= 8 and tris >= 512) or (frames_per_launch >= 4 and tris >= 8192))))
+            or (spp == 1 and frames_per_launch >= 8 and tris >= 512) or (frames_per_launch >= 4 and tris >= 8192))
 
 
 if __name__ == "__main__":
