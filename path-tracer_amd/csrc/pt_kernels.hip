@@ -1243,6 +1243,11 @@ __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uin
     return id;
 }
 
+// A tile's cost for the next plan is the sum over a fixed quarter of its pixels (the even ones of the even rows; a tile
+// starts at even coordinates, so every tile with a pixel in the image has one of them): a launch that measures pays one
+// global atomic per pixel job that reports, and the bench has 16 million pixel jobs per launch.
+__device__ __forceinline__ bool pt_cost_sample(uint32_t x, uint32_t y) { return ((x | y) & 1u) == 0u; }
+
 template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
 {
@@ -1722,7 +1727,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
                 if (finished) {
                     PT_FRESH_PARAMS(L);
-                    if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                    if (L.cost && pt_cost_sample(x, y)) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
                 } else if (HITS && retire) {
                     // The path is over and the job goes on: the pixel's next path is started by a pass over misses (a slot
                     // without a ray is one of theirs), where every lane starts a path, instead of here, where the few lanes
@@ -1913,7 +1918,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         if (frame == frame_end) {
                             finished = true;
                             mine = false;
-                            if (L.cost) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                            if (L.cost && pt_cost_sample(x, y)) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
                             add_retired();
                         } else {
                             // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
