@@ -2360,6 +2360,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(float4 *accum, const fl
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
     const uint2 ti = tile_items[(y / PT_TILE) * tiles_x + x / PT_TILE];
+    if (ti.y == 0u) return;  // a tile without items (its frames went straight onto the sums): nothing to add
     const uint32_t lane = (y % PT_TILE) * PT_TILE + x % PT_TILE;
     const size_t pix = (size_t)y * width + x;
     float4 a = accum[pix];
