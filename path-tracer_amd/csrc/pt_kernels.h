@@ -36,6 +36,7 @@
 #define PT_POOL_SHORT_MIN_TRIANGLES 512u
 #define PT_POOL_SHORT_BIG_MIN_FRAMES 4u
 #define PT_POOL_SHORT_BIG_MIN_TRIANGLES 8192u
+#define PT_POOL_HUGE_MESH_TRIANGLES (1u << 20)  // from here on the planner aims for twice as many work items
 #define PT_POOL_ONE_FRAME_MIN_TRIANGLES 8192u
 #define PT_POOL_ONE_FRAME_MIN_SAMPLES 48u
 #define PT_TILE_EARLY_SHADE_TRIANGLES 32768u  // per-tile kernel: meshes from this size on shade with fewer lanes waiting
