@@ -38,6 +38,7 @@ pub const PT_FLAG_DETAILED_STATS: u32 = 4;
 pub const PT_FLAG_TILE_KERNEL: u32 = 8;
 pub const PT_FLAG_POOL_KERNEL: u32 = 16;
 pub const PT_FLAG_TRIANGLE_MATERIALS: u32 = 32;
+pub const PT_FLAG_REGROUP_SHORT: u32 = 64;
 pub const PT_PRIM_NONE: u32 = 0xFFFF_FFFF;
 pub const PT_PRIM_SPHERE: u32 = 0x8000_0000;
 

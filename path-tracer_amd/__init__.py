@@ -29,6 +29,7 @@ PT_FLAG_DETAILED_STATS = 4
 PT_FLAG_TILE_KERNEL = 8
 PT_FLAG_POOL_KERNEL = 16
 PT_FLAG_TRIANGLE_MATERIALS = 32
+PT_FLAG_REGROUP_SHORT = 64
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
 

@@ -468,7 +468,7 @@ static int pt_set_flags_impl(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS | PT_FLAG_REGROUP_SHORT)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
@@ -762,6 +762,9 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     if ((spp_now == 1u && launch_frames >= PT_POOL_SHORT_MIN_FRAMES && ctx->n_tri_slots >= PT_POOL_SHORT_MIN_TRIANGLES) ||
         (launch_frames >= PT_POOL_SHORT_BIG_MIN_FRAMES && ctx->n_tri_slots >= PT_POOL_SHORT_BIG_MIN_TRIANGLES))
         use_pool = true;
+    // (regrouped short launches, PT_FLAG_REGROUP_SHORT: like the long ones; pooled / per-tile time 0.77-0.96 at 4 to 15
+    // frames on 192 to 69 k triangles)
+    if ((ctx->flags & PT_FLAG_REGROUP_SHORT) && launch_frames >= 4u && ctx->n_tri_slots >= PT_POOL_MIN_TRIANGLES) use_pool = true;
     if (ctx->flags & PT_FLAG_POOL_KERNEL) use_pool = true;
     if (ctx->flags & PT_FLAG_TILE_KERNEL) use_pool = false;
     if (const char *env = env_str("PTRT_KERNEL")) {  // "pool" / "tile": tuning builds only, overrides the flags
@@ -830,7 +833,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     // which is bit for bit the sum frame after frame (0 + x == x) while the frames run side by side instead of one
     // after the other per pixel.  From 16 frames on: items of several frames by measured cost (sums regrouped).
     sch.min_planned_frames = env_u32("PTRT_MIN_PLANNED", 2);
-    const uint32_t regroup_frames = 16;
+    const uint32_t regroup_frames = (ctx->flags & PT_FLAG_REGROUP_SHORT) ? 4 : 16;
     sch.probe_frames = 4;
     if (env_str("PTRT_NO_PLAN")) sch.min_planned_frames = 0xFFFFFFFFu;  // tuning aid
     sch.use_pool = use_pool;

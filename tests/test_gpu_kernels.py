@@ -170,3 +170,35 @@ def test_repeated_launches_reuse_their_plan(pt, po, scenes, flag):
             rays += ost["rays"]
     assert stats["rays"] == rays and stats["frames"] == 15 * n and (got[..., 3] == 15 * n).all()
     np.testing.assert_allclose(got, want, rtol=15 * n * 2.0 ** -23, atol=1e-6)
+
+
+def test_regrouped_short_launches(pt, po, scenes):
+    """PT_FLAG_REGROUP_SHORT: launches of 4 to 15 frames are split into items of several frames like longer ones -- the
+    same samples and ray counts as the oracle's frame-after-frame sums, equal up to fp32 summation order, reproducible
+    run to run; without the flag such a launch stays bit-identical to separate dispatches; launches of 2 and 3 frames
+    are exact either way."""
+    scene = scenes.bunny(n=12)
+    sky = scenes.sky_cube_direct(16)
+    st = pt.Settings(1, 6, 1e-4, 1000.0)
+    w, h = 160, 90
+    osc = po.from_scene(scene, w, h, st, sky)
+    for n in (3, 4, 9, 15):
+        want = np.zeros((h, w, 4), np.float32)
+        rays = 0
+        for f in range(n):
+            want, _, _, s = osc.render(50 + f, want)
+            rays += s["rays"]
+        got = []
+        for flags in (0, pt.PT_FLAG_REGROUP_SHORT, pt.PT_FLAG_REGROUP_SHORT):
+            r = pt.Renderer(scene, w, h, settings=st, flags=flags)
+            r.set_sky_cube(sky)
+            r.render_frames(50, 1, n)
+            got.append(r.read_sum())
+            assert r.stats()["rays"] == rays and (got[-1][..., 3] == n).all()
+            r.close()
+        assert np.array_equal(got[0].view(np.uint32), want.view(np.uint32)), f"{n} frames without the flag: not the sequential sums"
+        assert np.array_equal(got[1].view(np.uint32), got[2].view(np.uint32)), f"{n} frames regrouped: not reproducible"
+        if n < 4:
+            assert np.array_equal(got[1].view(np.uint32), want.view(np.uint32))
+        else:
+            np.testing.assert_allclose(got[1], want, rtol=n * 2.0 ** -23, atol=1e-6)
