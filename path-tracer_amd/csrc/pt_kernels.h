@@ -111,6 +111,8 @@ struct PtTraceParams {
     // pooled kernel only (filled in by pt_launch_trace)
     uint32_t *next_item;           // work-item counter, zero at launch
     uint32_t n_items;
+    uint32_t item_batch;           // work items a workgroup claims per trip to next_item
+    uint32_t cost_key;             // tiles_x | mask << 16: pixels with ((x | y) & mask) == 0 report their cost (0: all, 1: a quarter)
     uint32_t pool_start;           // an idle wave starts walking once this many rays of its group are pending
     uint32_t pool_topup;           // a walking wave takes more rays once this many of its walk slots are free
     uint32_t pool_dense;           // walkers that make a wave "walking" in that sense

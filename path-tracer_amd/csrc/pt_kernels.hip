@@ -1038,7 +1038,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
 #ifndef PT_PP_WAVES_PER_EU
 #define PT_PP_WAVES_PER_EU 4
 #endif
-#define PT_PP_ITEM_BATCH 4u  // work items claimed per trip to the launch's item counter
+#define PT_PP_ITEM_BATCH 8u  // most work items claimed per trip to the launch's item counter (half as many in launches with few items per workgroup)
+static_assert(PT_PP_ITEM_BATCH % 8u == 0, "item batches are staged four records at a time, whole or half");
 static_assert(PT_PP_PATHS % PT_PP_WAVES == 0 && PT_PP_PATHS <= PT_PP_QCAP && (PT_PP_QCAP & (PT_PP_QCAP - 1)) == 0, "pool geometry");
 static_assert(PT_PP_PATHS_WIDE % PT_PP_WAVES == 0 && PT_PP_PATHS_WIDE <= PT_PP_PATHS, "pool geometry");
 
@@ -1243,10 +1244,11 @@ __device__ __forceinline__ uint32_t ring_pop(pp_entry *ring, uint32_t *head, uin
     return id;
 }
 
-// A tile's cost for the next plan is the sum over a fixed quarter of its pixels (the even ones of the even rows; a tile
-// starts at even coordinates, so every tile with a pixel in the image has one of them): a launch that measures pays one
-// global atomic per pixel job that reports, and the bench has 16 million pixel jobs per launch.
-__device__ __forceinline__ bool pt_cost_sample(uint32_t x, uint32_t y) { return ((x | y) & 1u) == 0u; }
+// In long launches a tile's cost for the next plan is the sum over a fixed quarter of its pixels (mask 1: the even ones
+// of the even rows; a tile starts at even coordinates, so every tile with a pixel in the image has one of them): a launch
+// that measures pays one global atomic per pixel job that reports, and the bench has 16 million pixel jobs per launch.
+// Short launches (mask 0) let every pixel report: few jobs, and few frames to average a tile's cost over.
+__device__ __forceinline__ bool pt_cost_sample(uint32_t x, uint32_t y, uint32_t mask) { return ((x | y) & mask) == 0u; }
 
 template <bool STATS, bool GIZMO, bool SPP1, bool DIRECT>
 __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel(const PtTraceParams P)
@@ -1308,25 +1310,31 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             uint32_t pos = lds_load(&sh.staged_pos);
                             if (pos >= PT_PP_ITEM_BATCH) {
                                 // one trip to the launch's counter for a batch of items; their records are loaded side by side
-                                const uint32_t base = atomicAdd(L.next_item, (uint32_t)PT_PP_ITEM_BATCH);
-                                uint4 recs[PT_PP_ITEM_BATCH];
+                                const uint32_t nb = L.item_batch;  // (PT_PP_ITEM_BATCH or half of it: launch_pool)
+                                const uint32_t base = atomicAdd(L.next_item, nb);
+                                const uint32_t skip = PT_PP_ITEM_BATCH - nb;  // (the batch sits at the end of the staging array)
+                                // (four records at a time: eight would take the registers of a spill)
+#pragma nounroll
+                                for (uint32_t k0 = skip; k0 < PT_PP_ITEM_BATCH; k0 += 4u) {
+                                    uint4 recs[4];
 #pragma unroll
-                                for (uint32_t k = 0; k < PT_PP_ITEM_BATCH; k++) {
-                                    const uint32_t i = base + k;
-                                    recs[k] = make_uint4(0u, 0u, 0u, 0u);
-                                    if (i < L.n_items) {
-                                        if (DIRECT) recs[k] = make_uint4(i, 0u, L.n_frames, 0u);
-                                        else recs[k] = L.items[i];
+                                    for (uint32_t k = 0; k < 4u; k++) {
+                                        const uint32_t i = base + (k0 + k - skip);
+                                        recs[k] = make_uint4(0u, 0u, 0u, 0u);
+                                        if (i < L.n_items) {
+                                            if (DIRECT) recs[k] = make_uint4(i, 0u, L.n_frames, 0u);
+                                            else recs[k] = L.items[i];
+                                        }
+                                    }
+#pragma unroll
+                                    for (uint32_t k = 0; k < 4u; k++) {
+                                        lds_store(&sh.staged[k0 + k][0], recs[k].x);
+                                        lds_store(&sh.staged[k0 + k][1], recs[k].y);
+                                        lds_store(&sh.staged[k0 + k][2], recs[k].z);
+                                        lds_store(&sh.staged[k0 + k][3], base + (k0 + k - skip));
                                     }
                                 }
-#pragma unroll
-                                for (uint32_t k = 0; k < PT_PP_ITEM_BATCH; k++) {
-                                    lds_store(&sh.staged[k][0], recs[k].x);
-                                    lds_store(&sh.staged[k][1], recs[k].y);
-                                    lds_store(&sh.staged[k][2], recs[k].z);
-                                    lds_store(&sh.staged[k][3], base + k);
-                                }
-                                pos = 0;
+                                pos = skip;
                             }
                             tile = lds_load(&sh.staged[pos][0]);
                             f0 = lds_load(&sh.staged[pos][1]);
@@ -1727,7 +1735,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t cost = sh.st[F_COST][p] + 8u;  // a shading pass weighs like eight node visits
                 if (finished) {
                     PT_FRESH_PARAMS(L);
-                    if (L.cost && pt_cost_sample(x, y)) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                    if (L.cost && pt_cost_sample(x, y, L.cost_key >> 16)) atomicAdd(&L.cost[(y / PT_TILE) * (L.cost_key & 0xFFFFu) + x / PT_TILE], cost);
                 } else if (HITS && retire) {
                     // The path is over and the job goes on: the pixel's next path is started by a pass over misses (a slot
                     // without a ray is one of theirs), where every lane starts a path, instead of here, where the few lanes
@@ -1918,7 +1926,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         if (frame == frame_end) {
                             finished = true;
                             mine = false;
-                            if (L.cost && pt_cost_sample(x, y)) atomicAdd(&L.cost[(y / PT_TILE) * L.tiles_x + x / PT_TILE], cost);
+                            if (L.cost && pt_cost_sample(x, y, L.cost_key >> 16)) atomicAdd(&L.cost[(y / PT_TILE) * (L.cost_key & 0xFFFFu) + x / PT_TILE], cost);
                             add_retired();
                         } else {
                             // the pixel's next path (compute.wgsl:113-119, 131-136); depth >= 1, so it gets a ray
@@ -2531,11 +2539,17 @@ static hipError_t launch_pool(PtTraceParams p, uint32_t n_items, uint32_t stack_
     p.gstack_cap = stack_depth;
     const dim3 block(PT_PP_THREADS, 1, 1);
     const uint32_t want = (n_items + PT_PP_WAVES - 1u) / PT_PP_WAVES;
+    // items the launch really has: n_items is the table's size; a plan aims for wanted_items, or has one per tile and frame
+    p.cost_key = p.tiles_x | ((p.n_frames >= 64u ? 1u : 0u) << 16);  // (one word for the pixel job's report: fewer scalar registers)
+    const uint64_t est_items = p.items == nullptr ? n_items : (sch.max_chunk == 1u ? (uint64_t)p.n_tiles * p.n_frames : sch.wanted_items);
 #define PT_LAUNCH(ST, GZ, S1, DI)                                                                              \
     do {                                                                                                       \
         static const uint32_t per_cu = pool_groups_per_cu(pool_kernel<ST, GZ, S1, DI>);                        \
         uint32_t groups = sch.pool_groups ? sch.pool_groups : per_cu * sch.n_cus;                              \
         groups = std::max(1u, std::min(std::min(groups, want), pt_pool_max_groups(sch.n_cus)));                \
+        /* (a launch with fewer than 192 items per workgroup takes half batches: whole ones leave its last  */ \
+        /* items to too few groups -- 16 frames of the bench scene 1.95 against 2.06 ms)                     */ \
+        p.item_batch = est_items >= 192u * groups ? PT_PP_ITEM_BATCH : PT_PP_ITEM_BATCH / 2u;                   \
         hipLaunchKernelGGL((pool_kernel<ST, GZ, S1, DI>), dim3(groups, 1, 1), block, 0, stream, p);            \
     } while (0)
 #define PT_LAUNCH_DI(DI)                                                  \
