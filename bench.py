@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak (packed issue), spec
 HBM_PEAK_GBS = 8000.0
+INFINITY_CACHE_BYTES = 256 << 20  # memory-side cache in front of HBM: a working set below it is not served by HBM
 DEFAULT_SCALING = {"bunny_4k_d8_spp4096": "strong", "field_4k_d8_spp1024": "strong"}
 
 
@@ -53,6 +54,19 @@ def algorithmic_bytes(st: dict, pixel_frames: int) -> float:
     sky texel 16 B, accumulation 32 B per pixel and frame."""
     return (64.0 * st["interior"] + 52.0 * st["tri_tests"] + 48.0 * st["tri_accept"] + 16.0 * st["sky_lookups"]
             + 32.0 * pixel_frames)
+
+
+def working_set_bytes(scene) -> int:
+    """What a BVH walk reads, as the library stores it: 32 B per node and 64 B per triangle in the walk table, 48 B of
+    vertex normals per triangle."""
+    return 32 * int(len(scene.nodes)) + (64 + 48) * int(len(scene.triangles))
+
+
+def sky_loop_pixels(flags, w: int, h: int) -> int:
+    """Pixels of the image that lie in tiles flagged sky-only (8x8 tiles, the last ones clipped by the image)."""
+    import numpy as np
+    ty, tx = np.nonzero(flags)
+    return int((np.minimum(8, h - 8 * ty) * np.minimum(8, w - 8 * tx)).sum())
 
 
 def parse_args(argv=None):
@@ -212,39 +226,69 @@ def main():
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
     elapsed_max, rays_total = float(tt.item()), float(rr.item())
 
+    # What kind of rays those were.  Tiles whose camera rays provably all leave the scene are summed by a plain loop
+    # (sky_tiles_kernel: RNG, camera ray, sky texel, add -- no sphere or box test): flagged pixels x frames x samples of
+    # every timed launch.  The rest is the megakernel's; of those, the rays that entered the BVH below the root are counted
+    # by the detailed-stats build of the same kernel on the same frames (untimed; it renders every tile itself, the ray
+    # set is the same).  Its first launch also prices the algorithmic work of one launch for the roofline.
+    spp = max(settings.samples_per_pixel, 1)
+    sky_px = sky_loop_pixels(r.read_sky_tiles(), w, h)
+    launches = [frames_of_step(multi, rank, world, scaling, frames, i) for i in range(args.steps)]
+    sky_rays = sum(sky_px * l[2] * spp for l in launches)
+    r.set_flags(pt.PT_FLAG_DETAILED_STATS)
+    r.reset_ready_samples()
+    st, walked = None, 0
+    for l in launches:
+        r.render_frames(*l)
+        cum = r.stats()
+        if st is None:
+            st = dict(cum)
+        walked = cum["walks"]
+    r.set_flags(0)
+    kinds = torch.tensor([float(sky_rays), float(walked)], dtype=torch.float64, device=dev)
+    if reduce_steps:
+        dist.all_reduce(kinds, op=dist.ReduceOp.SUM)
+    sky_rays_total, walked_total = (int(x) for x in kinds.tolist())
+
     if rank == 0:
-        # algorithmic work of ONE launch of this rank, counted by the detailed-stats build of the same kernel on the
-        # same frames (untimed), priced with the work model above
-        launch = frames_of_step(multi, rank, world, scaling, frames, 0)
-        r.set_flags(pt.PT_FLAG_DETAILED_STATS)
-        r.reset_ready_samples()
-        r.render_frames(*launch)
-        st = r.stats()
-        r.set_flags(0)
+        launch = launches[0]
         flops, abytes = algorithmic_flops(st), algorithmic_bytes(st, w * h * launch[2])
         k_ms = float(np.mean(kernel_ms))
         k_s = k_ms * 1e-3
         valu_tflops = flops / k_s / 1e12
         valu_frac = valu_tflops / FP32_VALU_PEAK_TFLOPS
         traffic, traffic_src = find_traffic(args.workload, launch[2])
-        hbm_gbs = traffic / k_s / 1e9 if traffic else None
-        hbm_frac = hbm_gbs / HBM_PEAK_GBS if traffic else None
-        # The bound is the roof the launch sits closer to.  HBM: measured bytes (PMC, per launch) over the launch time --
-        # the algorithmic bytes below are mostly served by L2 / Infinity Cache and overstate what HBM has to deliver.
-        if hbm_frac is not None and hbm_frac > valu_frac:
-            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
+        fabric_gbs = traffic / k_s / 1e9 if traffic else None
+        fabric_frac = fabric_gbs / HBM_PEAK_GBS if traffic else None
+        # Which roof: where the walk's working set lives.  Nodes + triangles + normals below the Infinity Cache's size are
+        # served by L2 and that cache, not by HBM: the launch is bound by vector instruction issue and its figure is the
+        # fraction of the FP32 vector peak (the metric's own).  The traffic counter (TCC read/write requests to the fabric)
+        # then tallies cache-served misses too, so its rate is reported as `fabric_frac`, not as a fraction of an HBM roof.
+        # Only a working set beyond that cache (the 10 M-triangle field) makes the counter an HBM figure and HBM the bound.
+        ws = working_set_bytes(scene)
+        hbm_bound = ws > INFINITY_CACHE_BYTES
+        if hbm_bound and fabric_frac is not None:
+            roof = {"bound": "hbm", "achieved": fabric_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric_frac,
+                    "hbm_frac": fabric_frac, "hbm_traffic_GBps": fabric_gbs}
+        elif hbm_bound:
+            # no committed PMC record for this launch length: the algorithmic bytes stand in (an upper bound on HBM bytes)
+            roof = {"bound": "hbm", "achieved": abytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / k_s / 1e9 / HBM_PEAK_GBS,
+                    "hbm_frac": None, "hbm_traffic_GBps": None}
         else:
-            roof = {"bound": "valu", "achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac}
+            roof = {"bound": "valu", "achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac,
+                    "fabric_frac": fabric_frac, "fabric_traffic_GBps": fabric_gbs}
         roof.update({
-            "traffic": traffic, "traffic_source": traffic_src,
-            "valu_frac": valu_frac, "valu_TFLOPs": valu_tflops, "hbm_frac": hbm_frac, "hbm_traffic_GBps": hbm_gbs,
+            "traffic": traffic, "traffic_source": traffic_src, "working_set_bytes": ws,
+            "valu_frac": valu_frac, "valu_TFLOPs": valu_tflops,
             "kernel": "pool_kernel (+ accumulate_kernel; plan_kernel in two launches of every eight)" if r_uses_pool(pt, scene, settings, launch[2])
                       else "trace_kernel (+ plan_kernel and accumulate_kernel)",
             "kernel_ms": k_ms, "frames_per_launch": launch[2], "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": abytes, "algorithmic_GBps": abytes / k_s / 1e9,
             "note": "no MFMA: nothing here is a dense contraction; valu_frac prices the shader's own flop count against the packed-FP32 "
-                    "vector peak, hbm_frac the measured HBM bytes of one launch against 8 TB/s (null until a PMC record of this "
-                    "workload and launch length is committed under profiles/)"})
+                    "vector peak; traffic = memory-side bytes of one launch from the newest committed PMC record of this workload and "
+                    "launch length (null without one): an HBM figure only when the working set exceeds the 256 MiB Infinity Cache"})
+        rays_step = int(rays_total) // max(args.steps, 1)
+        sky_step, walked_step = sky_rays_total // max(args.steps, 1), walked_total // max(args.steps, 1)
         out = {
             "metric": "Mrays/s, bunny 1080p 8-bounce, 1/2/4/8 GPUs; % FP32 VALU peak",
             "value": rays_total / elapsed_max / 1e6, "unit": "Mrays/s",
@@ -256,7 +300,12 @@ def main():
                        "spp_per_step": (frames * world if scaling == "weak" else frames) * settings.samples_per_pixel,
                        "spp_per_gpu_per_step": launch[2] * settings.samples_per_pixel, "triangles": int(len(scene.triangles)),
                        "bvh_nodes": int(len(scene.nodes)), "bvh_depth": st["bvh_depth"], "sky_cube": args.sky_size,
-                       "rays_per_step": int(rays_total) // max(args.steps, 1),
+                       "rays_per_step": rays_step,
+                       # disjoint kinds, summing to rays_per_step (means over the timed steps): summed by the sky-only tiles' loop
+                       # without any intersection test; handled by the megakernel and ended at its sphere loop + root-box test;
+                       # handled by the megakernel and walked through the BVH
+                       "rays_sky_loop": sky_step, "rays_megakernel": rays_step - sky_step - walked_step, "rays_walked": walked_step,
+                       "sky_loop_beside": st["sky_loop_beside"],
                        "parallelism": f"sample-split x{world} ({scaling}), one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": roof,
         }

@@ -15,6 +15,12 @@ pub struct PtCtx {
     _private: [u8; 0],
 }
 
+/// Opaque group of renderer contexts, one per GPU (`pt_group`).
+#[repr(C)]
+pub struct PtGroup {
+    _private: [u8; 0],
+}
+
 /// `pt_stats_t`
 #[repr(C)]
 #[derive(Default, Debug, Clone, Copy, PartialEq, Eq)]
@@ -30,6 +36,8 @@ pub struct PtStats {
     pub sphere_accept: u64,
     pub frames: u64,
     pub bvh_depth: u64,
+    pub walks: u64,
+    pub sky_loop_beside: u64,
 }
 
 pub const PT_FLAG_REFERENCE_DISPATCH: u32 = 1;
@@ -39,6 +47,7 @@ pub const PT_FLAG_TILE_KERNEL: u32 = 8;
 pub const PT_FLAG_POOL_KERNEL: u32 = 16;
 pub const PT_FLAG_TRIANGLE_MATERIALS: u32 = 32;
 pub const PT_FLAG_REGROUP_SHORT: u32 = 64;
+pub const PT_GROUP_RCCL: u32 = 1;
 pub const PT_PRIM_NONE: u32 = 0xFFFF_FFFF;
 pub const PT_PRIM_SPHERE: u32 = 0x8000_0000;
 
@@ -72,6 +81,23 @@ extern "C" {
     pub fn pt_accum_device_ptr(ctx: *mut PtCtx) -> *mut c_void;
     pub fn pt_bind_accum(ctx: *mut PtCtx, device_ptr: *mut c_void) -> i32;
     pub fn pt_trace_rays(ctx: *mut PtCtx, origins: *const f32, dirs: *const f32, n: u32, prim: *mut u32, t: *mut f32, p: *mut f32, normal: *mut f32, front: *mut u32) -> i32;
+    pub fn pt_group_create(devices: *const i32, n: i32, width: u32, height: u32, flags: u32, out: *mut *mut PtGroup) -> i32;
+    pub fn pt_group_destroy(g: *mut PtGroup);
+    pub fn pt_group_last_error(g: *const PtGroup) -> *const c_char;
+    pub fn pt_group_size(g: *const PtGroup) -> i32;
+    pub fn pt_group_member(g: *mut PtGroup, i: i32) -> *mut PtCtx;
+    pub fn pt_group_set_flags(g: *mut PtGroup, flags: u32) -> i32;
+    pub fn pt_group_set_mesh(g: *mut PtGroup, tris: *const c_void, n_tris: u32, nodes: *const c_void, n_nodes: u32, tri_idx: *const u32, n_idx: u32) -> i32;
+    pub fn pt_group_set_sky_cube(g: *mut PtGroup, rgba32f: *const f32, size: u32) -> i32;
+    pub fn pt_group_set_sky_equirect(g: *mut PtGroup, rgba32f: *const f32, w: u32, h: u32, cube_size: u32) -> i32;
+    pub fn pt_group_set_camera(g: *mut PtGroup, camera64: *const c_void) -> i32;
+    pub fn pt_group_set_spheres(g: *mut PtGroup, sphere_data8208: *const c_void) -> i32;
+    pub fn pt_group_set_settings(g: *mut PtGroup, settings16: *const c_void) -> i32;
+    pub fn pt_group_render_frames(g: *mut PtGroup, time0: u32, n_frames: u32) -> i32;
+    pub fn pt_group_reduce(g: *mut PtGroup, root: i32) -> i32;
+    pub fn pt_group_reset(g: *mut PtGroup) -> i32;
+    pub fn pt_group_sync(g: *mut PtGroup) -> i32;
+    pub fn pt_group_stats(g: *mut PtGroup, out: *mut PtStats) -> i32;
     pub fn pt_bvh_build(tris: *const c_void, n_tris: u32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
     pub fn pt_plane_triangles(q: *const f32, u: *const f32, v: *const f32, albedo: *const f32, material: u32, tris_out: *mut c_void) -> i32;
     pub fn pt_pack_spheres(spheres8: *const f32, n: u32, sphere_data8208_out: *mut c_void) -> i32;
@@ -286,5 +312,81 @@ impl Renderer {
 impl Drop for Renderer {
     fn drop(&mut self) {
         unsafe { pt_destroy(self.ctx) }
+    }
+}
+
+/// Turns a status of a group call into a `Result` (message from `pt_group_last_error`).
+fn ok_group(code: i32, g: *const PtGroup) -> Result<(), PtError> {
+    if code == 0 {
+        Ok(())
+    } else {
+        Err(PtError { code, message: message(unsafe { pt_group_last_error(g) }) })
+    }
+}
+
+/// `Renderer` over all GPUs of a node, driven from this one thread: samples split across the GPUs by frame (frames are
+/// independent given their `time`, `compute.wgsl:85`), the per-GPU sums added onto GPU `devices[0]`'s by `reduce`.
+/// Same life cycle as `Renderer`: construct with the static scene, per-frame uniforms before rendering, reset on change.
+pub struct RendererGroup {
+    group: *mut PtGroup,
+    width: u32,
+    height: u32,
+    pub settings: Settings,
+}
+
+impl RendererGroup {
+    /// `rccl`: sum with RCCL's `ncclReduce` instead of peer copies added in a fixed order (`PT_GROUP_RCCL`).
+    pub fn new(devices: &[i32], width: u32, height: u32, triangles: &[u8], nodes: &[u8], triangle_indices: &[u32], hdr_file: &[u8], rccl: bool) -> Result<Self, PtError> {
+        let mut group: *mut PtGroup = std::ptr::null_mut();
+        let flags = if rccl { PT_GROUP_RCCL } else { 0 };
+        ok_group(unsafe { pt_group_create(devices.as_ptr(), devices.len() as i32, width, height, flags, &mut group) }, std::ptr::null())?;
+        let r = RendererGroup { group, width, height, settings: Settings::default() };
+        ok_group(
+            unsafe {
+                pt_group_set_mesh(group, triangles.as_ptr().cast(), (triangles.len() / 112) as u32, nodes.as_ptr().cast(), (nodes.len() / 32) as u32,
+                                  triangle_indices.as_ptr(), triangle_indices.len() as u32)
+            },
+            group,
+        )?;
+        let (pano, w, h) = decode_hdr(hdr_file)?;
+        ok_group(unsafe { pt_group_set_sky_equirect(group, pano.as_ptr(), w, h, 4096) }, group)?;
+        Ok(r)
+    }
+
+    /// The uniform uploads of `update_buffers` (`renderer.rs:518-548`) on every GPU, then frames
+    /// `time0 .. time0 + n_frames - 1` dealt over the GPUs (GPU g renders `time0 + g`, `time0 + g + G`, ...).
+    pub fn render_frames(&mut self, camera64: &[u8], sphere_data8208: &[u8], time0: u32, n_frames: u32) -> Result<(), PtError> {
+        assert!(camera64.len() == 64 && sphere_data8208.len() == 8208);
+        ok_group(unsafe { pt_group_set_camera(self.group, camera64.as_ptr().cast()) }, self.group)?;
+        ok_group(unsafe { pt_group_set_spheres(self.group, sphere_data8208.as_ptr().cast()) }, self.group)?;
+        ok_group(unsafe { pt_group_set_settings(self.group, bytemuck::bytes_of(&self.settings).as_ptr().cast()) }, self.group)?;
+        ok_group(unsafe { pt_group_render_frames(self.group, time0, n_frames) }, self.group)
+    }
+
+    /// Adds every GPU's sums onto the first GPU's (and clears the others'), then reads the fp32 mean over all frames
+    /// rendered since the last reset.
+    pub fn reduce_and_read_mean(&mut self) -> Result<Vec<f32>, PtError> {
+        ok_group(unsafe { pt_group_reduce(self.group, 0) }, self.group)?;
+        let root = unsafe { pt_group_member(self.group, 0) };
+        let mut out = vec![0f32; self.width as usize * self.height as usize * 4];
+        ok(unsafe { pt_read_mean_rgba32f(root, out.as_mut_ptr()) }, root)?;
+        Ok(out)
+    }
+
+    /// `reset_ready_samples` (`renderer.rs:635-637`) on every GPU.
+    pub fn reset_ready_samples(&mut self) {
+        let _ = unsafe { pt_group_reset(self.group) };
+    }
+
+    pub fn stats(&mut self) -> Result<PtStats, PtError> {
+        let mut s = PtStats::default();
+        ok_group(unsafe { pt_group_stats(self.group, &mut s) }, self.group)?;
+        Ok(s)
+    }
+}
+
+impl Drop for RendererGroup {
+    fn drop(&mut self) {
+        unsafe { pt_group_destroy(self.group) }
     }
 }

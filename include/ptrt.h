@@ -18,10 +18,12 @@
  * context (or, with NULL, of the last failed pt_create on this thread).  A context is
  * bound to one GPU and must be used from one host thread at a time.  Calls that launch
  * work are asynchronous on the context's stream unless they return data to the host.
- * Launches of two frames and more may run part of their kernels on two streams that the
- * context creates for itself (pt_create also runs two half-millisecond-bounded test kernels
- * on them); those streams are forked from and joined back into the context's stream inside
- * the call, so ordering on the context's stream is all a caller has to think about.
+ * Launches of two frames and more may run part of their kernels on a pair of streams that the
+ * library keeps per GPU (the first pt_create on a GPU creates them and runs two
+ * half-millisecond-bounded test kernels on them; they stay until the process ends and are
+ * shared by every context of that GPU); they are forked from and joined back into the
+ * context's stream inside the call, so ordering on the context's stream is all a caller has
+ * to think about.
  */
 #ifndef PTRT_H
 #define PTRT_H
@@ -81,6 +83,11 @@ typedef struct pt_stats_t {
     uint64_t sphere_accept; /* sphere hits that replaced the record (PT_FLAG_DETAILED_STATS only) */
     uint64_t frames;        /* dispatch-equivalents accumulated since the last pt_reset */
     uint64_t bvh_depth;     /* deepest leaf of the uploaded BVH = traversal stack bound */
+    uint64_t walks;         /* rays that entered the BVH below the root: they survived the sphere loop and the test of the
+                               root's two child boxes (PT_FLAG_DETAILED_STATS only) */
+    uint64_t sky_loop_beside; /* 1: this GPU's stream pair was found to run side by side when it was created, so planned
+                               launches run the loop over sky-only tiles beside the megakernel; 0: behind it, on the
+                               context's stream (same results, a few per cent slower) */
 } pt_stats_t;
 
 /* ---- lifetime: Renderer::new / drop (src/renderer.rs:32-37) ------------------------ */
@@ -194,6 +201,53 @@ int pt_bind_accum(pt_ctx *ctx, void *device_ptr);
  * p n x 3, normal n x 3, front n x u32. */
 int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim,
                   float *t, float *p, float *normal, uint32_t *front);
+
+/* ---- several GPUs of one node behind one handle ------------------------------------- */
+/* No counterpart in the reference, which drives one GPU.  Frames are independent given their `time` value
+ * (compute.wgsl:85 seeds the RNG with (x, y, x + time, y + time)), so samples split across GPUs by frame: member g of
+ * G renders time0 + g, time0 + g + G, ... into its own fp32 sums, the scene replicated on every GPU, nothing exchanged
+ * while rendering; pt_group_reduce then adds every member's sums onto one member.  For a host that drives all GPUs
+ * from one process and one thread; a host with one process per GPU uses pt_accum_device_ptr / pt_bind_accum and its
+ * own collective instead.  Every member is an ordinary context on a stream of its own; all calls below are
+ * asynchronous like their one-GPU counterparts (pt_group_sync waits for every member). */
+typedef struct pt_group pt_group;
+/* pt_group_create flag: sum with one RCCL ncclReduce(sum, float) per member inside ncclGroupStart/End (librccl is
+ * loaded with dlopen at that moment; PT_ERR_STATE if it cannot be) instead of the default: peer copies of the members'
+ * buffers onto the root's GPU, all at once, added there in member order -- a fixed summation order, so the result is
+ * bitwise the same from run to run.  RCCL needs the devices to be distinct. */
+#define PT_GROUP_RCCL 1u
+/* devices: n HIP device ordinals, one member each (the same ordinal may appear more than once without PT_GROUP_RCCL:
+ * its members then share that GPU). */
+int pt_group_create(const int *devices, int n, uint32_t width, uint32_t height, uint32_t flags, pt_group **out);
+void pt_group_destroy(pt_group *g);
+/* Message of the last failed call on this group (with NULL: of the last failed pt_group_create on this thread). */
+const char *pt_group_last_error(const pt_group *g);
+int pt_group_size(const pt_group *g);
+/* Member i's context, for the per-context calls (pt_read_*, pt_stats, pt_set_window ...); NULL if out of range.
+ * Owned by the group: not to be destroyed, and its stream not to be changed. */
+pt_ctx *pt_group_member(pt_group *g, int i);
+/* The per-context setters, applied to every member (the reference uploads these to its one GPU:
+ * renderer.rs:220-241, 518-548). */
+int pt_group_set_flags(pt_group *g, uint32_t flags);
+int pt_group_set_mesh(pt_group *g, const void *tris, uint32_t n_tris, const void *nodes, uint32_t n_nodes,
+                      const uint32_t *tri_idx, uint32_t n_idx);
+int pt_group_set_sky_cube(pt_group *g, const float *rgba32f, uint32_t size);
+int pt_group_set_sky_equirect(pt_group *g, const float *rgba32f, uint32_t w, uint32_t h, uint32_t cube_size);
+int pt_group_set_camera(pt_group *g, const void *camera64);
+int pt_group_set_spheres(pt_group *g, const void *sphere_data8208);
+int pt_group_set_settings(pt_group *g, const void *settings16);
+/* Frames time0 .. time0 + n_frames - 1 dealt over the members: member g renders pt_render_frames(time0 + g, G, its
+ * share) on its own GPU; the launches are queued on every GPU before any of them is waited for. */
+int pt_group_render_frames(pt_group *g, uint32_t time0, uint32_t n_frames);
+/* Adds every other member's sums (colour sums and frame counts) onto member `root`'s and clears the others', so that
+ * nothing is counted twice when the group goes on rendering and reduces again.  Afterwards pt_read_mean_rgba32f of
+ * pt_group_member(g, root) is the mean over all frames of all members since the last pt_group_reset; it differs from a
+ * one-GPU rendering of the same frames by fp32 summation order only. */
+int pt_group_reduce(pt_group *g, int root);
+int pt_group_reset(pt_group *g);
+int pt_group_sync(pt_group *g);
+/* Counters summed over the members (bvh_depth: the members' common value; sky_loop_beside: 1 if it is 1 everywhere). */
+int pt_group_stats(pt_group *g, pt_stats_t *out);
 
 /* ---- host-side scene construction (no GPU needed) ---------------------------------- */
 /* Bvh::from_triangles (src/scene/bvh.rs:34-66): same nodes and same index permutation.

@@ -30,6 +30,7 @@ PT_FLAG_TILE_KERNEL = 8
 PT_FLAG_POOL_KERNEL = 16
 PT_FLAG_TRIANGLE_MATERIALS = 32
 PT_FLAG_REGROUP_SHORT = 64
+PT_GROUP_RCCL = 1
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
 
@@ -56,7 +57,8 @@ class PtError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "interior", "tri_tests", "tri_accept", "sphere_tests",
-                                          "sky_lookups", "bounces", "sphere_accept", "frames", "bvh_depth")]
+                                          "sky_lookups", "bounces", "sphere_accept", "frames", "bvh_depth", "walks",
+                                          "sky_loop_beside")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -105,6 +107,23 @@ ABI = [
     ("pt_accum_device_ptr", _VP, [_VP]),
     ("pt_bind_accum", _I, [_VP, _VP]),
     ("pt_trace_rays", _I, [_VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP]),
+    ("pt_group_create", _I, [C.POINTER(_I), _I, _U32, _U32, _U32, C.POINTER(_VP)]),
+    ("pt_group_destroy", None, [_VP]),
+    ("pt_group_last_error", C.c_char_p, [_VP]),
+    ("pt_group_size", _I, [_VP]),
+    ("pt_group_member", _VP, [_VP, _I]),
+    ("pt_group_set_flags", _I, [_VP, _U32]),
+    ("pt_group_set_mesh", _I, [_VP, _VP, _U32, _VP, _U32, _VP, _U32]),
+    ("pt_group_set_sky_cube", _I, [_VP, _VP, _U32]),
+    ("pt_group_set_sky_equirect", _I, [_VP, _VP, _U32, _U32, _U32]),
+    ("pt_group_set_camera", _I, [_VP, _VP]),
+    ("pt_group_set_spheres", _I, [_VP, _VP]),
+    ("pt_group_set_settings", _I, [_VP, _VP]),
+    ("pt_group_render_frames", _I, [_VP, _U32, _U32]),
+    ("pt_group_reduce", _I, [_VP, _I]),
+    ("pt_group_reset", _I, [_VP]),
+    ("pt_group_sync", _I, [_VP]),
+    ("pt_group_stats", _I, [_VP, C.POINTER(Stats)]),
     ("pt_bvh_build", C.c_int64, [_VP, _U32, _VP, _VP]),
     ("pt_plane_triangles", _I, [_VP, _VP, _VP, _VP, _U32, _VP]),
     ("pt_pack_spheres", _I, [_VP, _U32, _VP]),
@@ -432,3 +451,101 @@ class Renderer:
         self._ck(self._l.pt_trace_rays(self._ctx, _ptr(origins), _ptr(dirs), n, _ptr(prim), _ptr(t), _ptr(p),
                                        _ptr(nrm), _ptr(front)))
         return prim, t, p, nrm, front
+
+
+class RendererGroup:
+    """pt_group_*: one Renderer per GPU behind one handle, driven from this one thread.  Frames are dealt over the members
+    (member g renders time0 + g, time0 + g + G, ...: frames are independent given their time value, compute.wgsl:85) and
+    `reduce` adds every member's sums onto one member's."""
+
+    def __init__(self, scene: Scene, width: int, height: int, devices: Sequence[int], settings: Optional[Settings] = None,
+                 flags: int = 0, group_flags: int = 0):
+        self._l = lib()
+        self._g = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._l.pt_group_create(devs, len(devices), width, height, group_flags, C.byref(self._g))
+        if rc != 0:
+            raise PtError(rc, self._l.pt_group_last_error(None).decode())
+        self.width, self.height, self.devices = width, height, list(devices)
+        self.settings = settings or Settings()
+        if flags or _forced_flags:
+            self.set_flags(flags)
+        tri = np.ascontiguousarray(scene.triangles, TRIANGLE_DTYPE)
+        nodes = np.ascontiguousarray(scene.nodes, NODE_DTYPE)
+        idx = np.ascontiguousarray(scene.triangle_indices, np.uint32)
+        self._ck(self._l.pt_group_set_mesh(self._g, _ptr(tri), len(tri), _ptr(nodes), len(nodes), _ptr(idx), len(idx)))
+        self.update_scene(scene)
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise PtError(rc, self._l.pt_group_last_error(self._g).decode())
+
+    def close(self):
+        if self._g:
+            self._l.pt_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._l.pt_group_size(self._g))
+
+    def set_flags(self, flags: int):
+        if not flags & (PT_FLAG_POOL_KERNEL | PT_FLAG_TILE_KERNEL):
+            flags |= _forced_flags
+        self._ck(self._l.pt_group_set_flags(self._g, flags))
+
+    def update_scene(self, scene: Scene):
+        cam, sph, st = scene.camera.buffer(), pack_spheres(scene.spheres), self.settings.buffer()
+        self._ck(self._l.pt_group_set_camera(self._g, _ptr(cam)))
+        self._ck(self._l.pt_group_set_spheres(self._g, _ptr(sph)))
+        self._ck(self._l.pt_group_set_settings(self._g, _ptr(st)))
+
+    def set_sky_cube(self, faces: np.ndarray):
+        faces = np.ascontiguousarray(faces, np.float32)
+        assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 4
+        self._ck(self._l.pt_group_set_sky_cube(self._g, _ptr(faces), faces.shape[1]))
+
+    def set_sky_equirect(self, pano: np.ndarray, cube_size: int):
+        pano = np.ascontiguousarray(pano, np.float32)
+        assert pano.ndim == 3 and pano.shape[2] == 4
+        self._ck(self._l.pt_group_set_sky_equirect(self._g, _ptr(pano), pano.shape[1], pano.shape[0], cube_size))
+
+    def render_frames(self, time0: int, n_frames: int):
+        self._ck(self._l.pt_group_render_frames(self._g, time0 & 0xFFFFFFFF, n_frames))
+
+    def reduce(self, root: int = 0):
+        self._ck(self._l.pt_group_reduce(self._g, root))
+
+    def reset_ready_samples(self):
+        self._ck(self._l.pt_group_reset(self._g))
+
+    def sync(self):
+        self._ck(self._l.pt_group_sync(self._g))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._ck(self._l.pt_group_stats(self._g, C.byref(s)))
+        return s.as_dict()
+
+    def _member_call(self, i: int, fn, *args):
+        ctx = self._l.pt_group_member(self._g, i)
+        if not ctx:
+            raise PtError(-1, f"member {i} out of range")
+        rc = fn(C.c_void_p(ctx), *args)
+        if rc != 0:
+            raise PtError(rc, self._l.pt_last_error(C.c_void_p(ctx)).decode())
+
+    def read_sum(self, member: int = 0) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._member_call(member, self._l.pt_read_sum_rgba32f, _ptr(out))
+        return out
+
+    def read_mean(self, member: int = 0) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._member_call(member, self._l.pt_read_mean_rgba32f, _ptr(out))
+        return out

@@ -71,6 +71,7 @@ struct pt_ctx {
     uint2 *tile_items = nullptr;
     uint32_t *tile_sky = nullptr;  // per tile: sees only the sky (PtSchedule::tile_sky)
     // planned launches with sky-only tiles: the megakernel on main_stream, the tiles' loop beside it on side_stream
+    // (the GPU's pair, g_streams: borrowed, never destroyed by a context)
     hipStream_t main_stream = nullptr, side_stream = nullptr;
     hipEvent_t fork_event = nullptr, start_event = nullptr, join_event = nullptr, main_event = nullptr;
     uint4 *items = nullptr;
@@ -137,6 +138,50 @@ hipError_t static_scratch_init(int device)
     if (!p || (reinterpret_cast<uintptr_t>(p) & 255u)) return hipErrorInvalidSymbol;
     g_static[device].ptr = static_cast<unsigned char *>(p);
     return hipSuccess;
+}
+
+// ---- one stream pair per GPU ---------------------------------------------------------------------------------------
+// Planned launches run the megakernel on `main` and the sky-only tiles' loop beside it on `side`; both are forked from
+// and joined back into the caller's stream by events of the context.  The pair belongs to the device, not to a context:
+// it is created once, by the first pt_create on that GPU, tested once (pt_streams_run_side_by_side: do the two reach
+// the GPU through different hardware queues?) and then kept until the process ends, whatever contexts come and go.
+// A runtime hands its few hardware queues (4 per process by default) to streams as they are created and destroyed, so
+// a pair per context meant up to five stream creations per pt_create and a queue assignment that depended on the
+// order in which a host made and dropped its renderers; one fixed pair has one assignment, checked once, and
+// pt_stats reports the check's verdict.  Both streams have the default priority: a stream of another priority reaches
+// the GPU through a queue that the command processor serves strictly before (or after) the caller's, and a wait of the
+// preferred queue on an event of the other one is then a priority inversion.  Launches of several contexts simply
+// queue up on the pair (they could not overlap anyway: a megakernel fills the GPU).
+struct DeviceStreams {
+    std::mutex lock;
+    bool tried = false;          // creation and test have run (successfully or not)
+    hipStream_t main = nullptr;  // null: creation failed, launches stay on the caller's stream
+    hipStream_t side = nullptr;  // null: no stream was found that runs beside `main`; the loop runs behind the megakernel
+    uint32_t *words = nullptr;   // 4 device words for the test kernels
+} g_streams[kMaxDevices];
+
+// Once per device, with that device current (pt_create calls it).  Failures are not errors: without the pair every
+// launch runs on the caller's stream alone.
+void device_streams_init(int device)
+{
+    DeviceStreams &ds = g_streams[device];
+    std::lock_guard<std::mutex> g(ds.lock);
+    if (ds.tried) return;
+    ds.tried = true;
+    if (hipMalloc((void **)&ds.words, 4 * sizeof(uint32_t)) != hipSuccess) { ds.words = nullptr; return; }
+    if (hipStreamCreateWithFlags(&ds.main, hipStreamNonBlocking) != hipSuccess) { ds.main = nullptr; return; }
+    // A candidate that shares the main stream's queue is set aside -- and kept until the search is over, so that the
+    // next stream created is given another queue -- and the next one tried.
+    hipStream_t rejected[4];
+    int n_rejected = 0;
+    for (int attempt = 0; attempt < 4 && !ds.side; attempt++) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        bool beside = false;
+        if (pt_streams_run_side_by_side(ds.main, cand, ds.words, &beside) == hipSuccess && beside) ds.side = cand;
+        else rejected[n_rejected++] = cand;
+    }
+    for (int k = 0; k < n_rejected; k++) (void)hipStreamDestroy(rejected[k]);
 }
 
 thread_local std::string g_create_error;
@@ -247,9 +292,15 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
 // at most half a pixel, has the direction pixel00 + px du + py dv - origin (compute.wgsl:109-119); a point P of a box is
 // seen along (px, py) = (a / c, b / c) where (a, b, c) solves [du dv pixel00-origin] (a, b, c)^T = P - origin, c > 0.
 // The image of a convex box is the hull of its corners' images, so a pixel more than the jitter outside their
-// bounding rectangle sees nothing of the box; two pixels of margin cover the jitter and every rounding on the way
-// (double arithmetic here against the kernels' float slab test, whose error is some 1e-7 of the distances).  A box
-// with a corner at or behind the camera gets no statement.
+// bounding rectangle sees nothing of the box.  The margin: two pixels for the jitter, plus what the kernels' float
+// arithmetic can move a ray or a box by, in pixels.  The direction is evaluated in float as pixel00 + x du + y dv +
+// jitter - origin, every step rounding to an ulp of its largest intermediate M = |pixel00| + W |du| + H |dv| + |origin|:
+// an error of a few 2^-24 M in world units = that over |du| (or |dv|) in pixels -- negligible near the origin at an
+// ordinary field of view, more than two pixels for a narrow one far from it (5 degrees at 1080p, 1000 units out).  The
+// slab test evaluates (bound - origin) / direction in float: it sees each box face up to a few ulps of B = the largest
+// |bound| or |origin| away from where it is, which moves the face's image by that over (c |du|) pixels, c the corner's
+// depth in units of |pixel00 - origin|.  Sixteen ulps each (the evaluations have at most five roundings) bound both;
+// if the sum exceeds 64 pixels, or a box has a corner at or behind the camera, there is no statement for that box.
 void camera_cull_rects(const pt_ctx *ctx, const pt_frame &fr, uint32_t cull[8])
 {
     for (int k = 0; k < 2; k++) { cull[4 * k] = 0; cull[4 * k + 1] = 0xFFFFFFFFu; cull[4 * k + 2] = 0; cull[4 * k + 3] = 0xFFFFFFFFu; }
@@ -261,6 +312,14 @@ void camera_cull_rects(const pt_ctx *ctx, const pt_frame &fr, uint32_t cull[8])
                        m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
     if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return;
     const float4 *q = ctx->root_pair;  // {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x} {lmax.y rmax.y lmax.z rmax.z}
+    auto len3 = [](double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); };
+    const double eps = 1.0 / 16777216.0;  // 2^-24: half an ulp of a float in [1, 2)
+    const double step = std::min(len3(fr.du.x, fr.du.y, fr.du.z), len3(fr.dv.x, fr.dv.y, fr.dv.z));  // world units per pixel
+    const double lo_o = len3(fr.origin.x, fr.origin.y, fr.origin.z);
+    const double M = len3(fr.pixel00.x, fr.pixel00.y, fr.pixel00.z) + (double)ctx->width * len3(fr.du.x, fr.du.y, fr.du.z) +
+                     (double)ctx->height * len3(fr.dv.x, fr.dv.y, fr.dv.z) + lo_o;
+    if (!(step > 0.0) || !std::isfinite(M)) return;
+    double cmin[2] = {1e300, 1e300}, B[2] = {lo_o, lo_o};
     for (int k = 0; k < 2; k++) {
         const double lo[3] = {k ? q[0].y : q[0].x, k ? q[0].w : q[0].z, k ? q[1].y : q[1].x};
         const double hi[3] = {k ? q[1].w : q[1].z, k ? q[2].y : q[2].x, k ? q[2].w : q[2].z};
@@ -273,13 +332,16 @@ void camera_cull_rects(const pt_ctx *ctx, const pt_frame &fr, uint32_t cull[8])
             const double b = (m[0][0] * (v[1] * m[2][2] - m[1][2] * v[2]) - v[0] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * v[2] - v[1] * m[2][0])) / det;
             const double cc = (m[0][0] * (m[1][1] * v[2] - v[1] * m[2][1]) - m[0][1] * (m[1][0] * v[2] - v[1] * m[2][0]) + v[0] * (m[1][0] * m[2][1] - m[1][1] * m[2][0])) / det;
             if (!(cc > 1e-6) || !std::isfinite(a) || !std::isfinite(b)) { ok = false; break; }  // at or behind the camera
+            cmin[k] = std::min(cmin[k], cc);
+            B[k] = std::max(B[k], std::max(std::max(std::fabs(v[0] + fr.origin.x), std::fabs(v[1] + fr.origin.y)), std::fabs(v[2] + fr.origin.z)));
             const double px = a / cc, py = b / cc;
             if (!std::isfinite(px) || !std::isfinite(py)) { ok = false; break; }
             x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
         }
         if (!ok) continue;
-        const double margin = 2.0;
         const double W = ctx->width, H = ctx->height;
+        const double margin = 2.0 + 16.0 * eps * (M / step + B[k] / (step * cmin[k]));
+        if (!(margin <= 64.0)) continue;  // (also when it is not a number)
         const double ax0 = std::floor(x0 - margin), ax1 = std::ceil(x1 + margin), ay0 = std::floor(y0 - margin), ay1 = std::ceil(y1 + margin);
         if (ax1 < 0.0 || ay1 < 0.0 || ax0 > W - 1.0 || ay0 > H - 1.0) {  // entirely off screen
             cull[4 * k] = 0xFFFFFFFFu; cull[4 * k + 1] = 0; cull[4 * k + 2] = 0xFFFFFFFFu; cull[4 * k + 3] = 0;
@@ -369,25 +431,12 @@ static int pt_create_impl(int device, uint32_t width, uint32_t height, pt_ctx **
     if (rc == PT_OK) step(hipMalloc((void **)&ctx->tile_sky, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_sky, 0, n_tiles * sizeof(uint32_t)), "tile flags");
     if (rc == PT_OK) step(hipMemset(ctx->tile_cost, 0, n_tiles * sizeof(uint32_t)), "clear");
-    if (rc == PT_OK) step(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking), "main stream");
     if (rc == PT_OK) {
-        // The side stream has to reach the GPU through another hardware queue than the main stream, or its kernel runs
-        // behind the megakernel instead of beside it.  A process's streams share a few queues (4 by default), handed
-        // out as streams come and go, so the pair is tested, and a stream that shares the main stream's queue is set
-        // aside (kept until the search is over, so that the next one created gets another queue) and the next one tried.
-        hipStream_t rejected[4];
-        int n_rejected = 0;
-        for (int attempt = 0; attempt < 4 && rc == PT_OK && !ctx->side_stream; attempt++) {
-            hipStream_t cand = nullptr;
-            step(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking), "side stream");
-            if (rc != PT_OK) break;
-            bool beside = false;
-            step(pt_streams_run_side_by_side(ctx->main_stream, cand, ctx->next_item + 8, &beside), "stream test");
-            if (rc == PT_OK && beside) ctx->side_stream = cand;
-            else rejected[n_rejected++] = cand;
-        }
-        for (int k = 0; k < n_rejected; k++) (void)hipStreamDestroy(rejected[k]);
-        // (no such stream found: the loop runs on the launch stream behind the megakernel, as without sky-only tiles)
+        // the GPU's stream pair (created and tested by the first context on this GPU, shared by all of them)
+        device_streams_init(device);
+        ctx->main_stream = g_streams[device].main;
+        ctx->side_stream = g_streams[device].main ? g_streams[device].side : nullptr;
+        // (no pair that runs side by side: the loop runs on the launch stream behind the megakernel, as without sky-only tiles)
     }
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming), "event");
     if (rc == PT_OK) step(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming), "event");
@@ -425,11 +474,7 @@ void pt_destroy(pt_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     else (void)hipDeviceSynchronize();
-    for (hipStream_t own : {ctx->main_stream, ctx->side_stream}) {
-        if (!own) continue;
-        (void)hipStreamSynchronize(own);
-        (void)hipStreamDestroy(own);
-    }
+    // (the GPU's stream pair is not the context's to destroy; every launch joined it back into the context's stream)
     if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
     if (ctx->start_event) (void)hipEventDestroy(ctx->start_event);
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
@@ -1027,9 +1072,10 @@ int check_gave_up(pt_ctx *ctx)
     PT_HIP(ctx, hipMemcpy(w, ctx->next_item + 1, sizeof w, hipMemcpyDeviceToHost));
     if (w[0] || w[1])
         return fail(ctx, PT_ERR_INTERNAL,
-                    "pooled kernel: %u waves gave up waiting%s%s%s%s; the accumulated image is incomplete (pt_reset and use PT_FLAG_TILE_KERNEL)", w[0],
+                    "pooled kernel: %u waves gave up waiting%s%s%s%s%s; the accumulated image is incomplete (pt_reset and use PT_FLAG_TILE_KERNEL)", w[0],
                     (w[1] & 1u) ? "; a ring entry was overwritten" : "", (w[1] & 2u) ? "; a claimed ring entry was never filled" : "",
-                    (w[1] & 4u) ? "; a ring held a slot id beyond the pool" : "", (w[1] & 8u) ? "; a slot's sums index was out of range" : "");
+                    (w[1] & 4u) ? "; a ring held a slot id beyond the pool" : "", (w[1] & 8u) ? "; a slot's sums index was out of range" : "",
+                    (w[1] & 16u) ? "; the hand-out of pixel jobs ran out of its bounded wait" : "");
     return PT_OK;
 }
 }  // namespace
@@ -1169,6 +1215,8 @@ static int pt_stats_impl(pt_ctx *ctx, pt_stats_t *out)
     out->sphere_accept = c[8];
     out->frames = ctx->frames;
     out->bvh_depth = ctx->bvh_depth;
+    out->walks = c[9];
+    out->sky_loop_beside = (ctx->main_stream && ctx->side_stream) ? 1u : 0u;
     return check_gave_up(ctx);
 }
 

@@ -55,7 +55,7 @@
 #define PT_POOL_MISS_ITERS 32u
 #define PT_POOL_MISS_LANES 48u
 #define PT_POOL_MAX_IDLE (1u << 22)
-#define PT_NUM_COUNTERS 9   // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept
+#define PT_NUM_COUNTERS 10  // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept, walks
 
 struct PtDeviceScene {
     // spheres: 3 float4 each {center, radius} {albedo, material} {1/radius, 0, 0, 0}

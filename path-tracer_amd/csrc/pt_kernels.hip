@@ -51,7 +51,8 @@ struct Stack {
 };
 
 struct Counters {
-    uint32_t rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept;
+    uint32_t rays = 0, paths = 0, interior = 0, tri_tests = 0, tri_accept = 0, sphere_tests = 0, sky = 0, bounces = 0, sphere_accept = 0;
+    uint32_t walks = 0;  // rays that went on into the BVH after the sphere loop and the root visit
 };
 
 // Closest-hit record kept in registers during traversal; the full record (point, normal,
@@ -140,7 +141,7 @@ __device__ __forceinline__ bool pt_camera_ray_misses_bvh(const uint32_t (&cull)[
 // skip_root: the caller knows that this ray enters neither of the root's child boxes (a camera ray of a pixel outside
 // their screen rectangles): the root visit is counted but not computed.
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root = false)
+__device__ __forceinline__ bool walk_begin_body(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root)
 {
     Closest rec;
     rec.hit = false;
@@ -212,6 +213,16 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
     w.node = k1;
     if (d2 < w.nearest) stack.push(w.sp++, k2);
     return true;
+}
+
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root = false)
+{
+    const bool need = walk_begin_body<STATS>(sc, ray, w, stack, cn, skip_root);
+    // (added, not branched on: an increment in a branch of its own gets merged with the neighbouring branches' increments
+    // of other counters into one store through a selected address, which keeps the counters out of registers)
+    if (STATS) cn.walks += need ? 1u : 0u;
+    return need;
 }
 
 // One node visit.  Returns true when the walk is over (stack empty, compute.wgsl:264, 292).
@@ -701,6 +712,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// A wave's counts onto its stripe of the launch's counters: one atomic per wave and counter (word k of the stripe =
+// counter k of PT_NUM_COUNTERS; word 1, the paths, is counted on the host).
+template <bool STATS>
+__device__ __forceinline__ void pt_add_counters(unsigned long long *stripe_words, const Counters &cn, uint32_t lane)
+{
+    auto add = [&](uint32_t k, uint32_t v) {
+        const uint32_t s = wave_sum(v);
+        if (lane == 0 && s) atomicAdd(&stripe_words[k], (unsigned long long)s);
+    };
+    add(0, cn.rays);
+    if (STATS) {
+        add(2, cn.interior); add(3, cn.tri_tests); add(4, cn.tri_accept); add(5, cn.sphere_tests);
+        add(6, cn.sky); add(7, cn.bounces); add(8, cn.sphere_accept); add(9, cn.walks);
+    }
+}
+
 // The kernel's parameter block is large (scene pointers, camera frame, the root's child boxes).  Kept
 // in scalar registers for the whole persistent loop it overflows them, and every spilled value costs
 // vector instructions in the walk loop.  The shading pass and the job hand-out therefore re-read the
@@ -790,7 +817,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     unsigned long long diag_a = 0, diag_b = 0, diag_c = 0, diag_s = 0;
     uint32_t diag_steps = 0;
 #endif
-    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cn;
     const bool in_image = (x < P.cols) && (y < P.rows) && frame_begin < frame_end && P.spp > 0;
     bool active = in_image;
 
@@ -967,13 +994,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     }
 #endif
     // one atomic per wave and counter
-    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
-    const int ncount = STATS ? PT_NUM_COUNTERS : 1;  // paths are counted on the host
-    for (int k = 0; k < ncount; k++) {
-        if (k == 1) continue;
-        const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&P.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH + k], (unsigned long long)s);
-    }
+    unsigned long long *const stripe_words = &P.counters[(blockIdx.x % PT_COUNTER_STRIPES) * PT_COUNTER_PITCH];
+    pt_add_counters<STATS>(stripe_words, cn, lane);
 }
 
 #ifndef PT_POOL_PIPELINED_WALK
@@ -1146,6 +1168,7 @@ struct PPStack {
 #define PT_KERR_RING_EMPTY 2u      // a claimed ring position was never filled (slot id lost)
 #define PT_KERR_SLOT_ID 4u         // a ring handed out a slot id beyond the pool
 #define PT_KERR_SUMS_INDEX 8u      // a slot's index into the sums lies outside the buffer
+#define PT_KERR_JOB_WAIT 16u       // the hand-out of pixel jobs ran out of its bounded wait (lock held, or the claim kept losing)
 __device__ __forceinline__ void pt_mark_error(uint32_t bit)
 {
     PtTraceParams L;  // (re-read: only the word of the error pointer is loaded)
@@ -1273,7 +1296,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     __syncthreads();
 
     PPStack stack{&sh.stack[0][tid], P.gstack ? P.gstack + ((size_t)blockIdx.x * PT_PP_THREADS + tid) : nullptr, gridDim.x * PT_PP_THREADS};
-    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cn;
 
     // Gives each lane with `need` a job for slot p, in lane order, from the group's open work item
     // (opening the next one when its 64 pixels are handed out); false for the lanes left without a
@@ -1287,7 +1310,8 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             if (nm == 0ull) break;
             uint32_t first = 0, take = 0, x0 = 0, y0 = 0, fb = 0, fend = 0, index = 0;
             if (lane == 0) {
-                for (uint32_t spin = 0; spin < PT_PP_MAX_SPIN; spin++) {
+                uint32_t spin = 0;
+                for (; spin < PT_PP_MAX_SPIN; spin++) {
                     const uint32_t jw = lds_load(&sh.job_word);  // generation << 8 | pixels handed out
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const uint32_t done = jw & 0xFFu;
@@ -1356,6 +1380,9 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     lds_store(&sh.job_lock, 0u);
                 }
+                // (the loop is left by a claim or by the end of the items; running out of trips -- the lock never released,
+                // the claim lost a million times -- would otherwise pass for "no items left" and drop the staged items silently)
+                if (spin >= PT_PP_MAX_SPIN) pt_mark_error(PT_KERR_JOB_WAIT);
             }
             take = __builtin_amdgcn_readfirstlane(take);
             if (take == 0u) break;  // no items left
@@ -2133,13 +2160,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     PtTraceParams LE;  // (re-read: the counters' address is not kept in registers through the loop)
     pt_fresh_params(LE);
     const uint32_t stripe = lds_load_uniform(&sh.group) % PT_COUNTER_STRIPES;
-    uint32_t vals[PT_NUM_COUNTERS] = {cn.rays, cn.paths, cn.interior, cn.tri_tests, cn.tri_accept, cn.sphere_tests, cn.sky, cn.bounces, cn.sphere_accept};
-    const int ncount = STATS ? PT_NUM_COUNTERS : 1;
-    for (int k = 0; k < ncount; k++) {
-        if (k == 1) continue;
-        const uint32_t s = wave_sum(vals[k]);
-        if (lane == 0 && s) atomicAdd(&LE.counters[stripe * PT_COUNTER_PITCH + k], (unsigned long long)s);
-    }
+    pt_add_counters<STATS>(&LE.counters[stripe * PT_COUNTER_PITCH], cn, lane);
 }
 
 // ---- explicit ray queries ---------------------------------------------------------------
@@ -2158,7 +2179,7 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     Ray r;
     r.o = V3(Q.origins[3 * i], Q.origins[3 * i + 1], Q.origins[3 * i + 2]);
     r.d = V3(Q.dirs[3 * i], Q.dirs[3 * i + 1], Q.dirs[3 * i + 2]);
-    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counters cn;
     const Closest c = hit_scene<false>(Q.sc, r, stack, cn);
     const HitRecord h = make_record(Q.sc, r, c);
     if (Q.prim) Q.prim[i] = h.prim;

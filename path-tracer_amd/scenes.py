@@ -160,4 +160,8 @@ CONFIGS = {
     "bunny_1080p_d8_spp256": (bunny, 1920, 1080, Settings(1, 8, 1e-4, 1000.0), 256),
     "bunny_4k_d8_spp4096": (bunny, 3840, 2160, Settings(1, 8, 1e-4, 1000.0), 4096),
     "field_4k_d8_spp1024": (instanced_field, 3840, 2160, Settings(1, 8, 1e-4, 1000.0), 1024),
+    # the reference's own per-frame call: one dispatch of 1 spp per step (Renderer::render, renderer.rs:562-570),
+    # at its default depth (renderer.rs:411-416) and at the benchmark's
+    "interactive_1080p_d32_spp1": (bunny, 1920, 1080, Settings(1, 32, 1e-4, 1000.0), 1),
+    "interactive_1080p_d8_spp1": (bunny, 1920, 1080, Settings(1, 8, 1e-4, 1000.0), 1),
 }

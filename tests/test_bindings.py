@@ -12,7 +12,7 @@ def _c_functions():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = text[text.index("typedef struct pt_stats_t"):]
     out = []
-    for m in re.finditer(r"^(const char \*|void \*|void|int64_t|int)\s*(pt_\w+)\(([^;]*?)\);", text, flags=re.M | re.S):
+    for m in re.finditer(r"^(const char \*|void \*|pt_ctx \*|void|int64_t|int)\s*(pt_\w+)\(([^;]*?)\);", text, flags=re.M | re.S):
         params = m.group(3).strip()
         n = 0 if params in ("", "void") else len(params.split(","))
         out.append((m.group(2), n, m.group(1).strip()))
@@ -33,9 +33,9 @@ def _rust_functions():
 
 def test_extern_block_matches_header():
     c, rust = _c_functions(), _rust_functions()
-    assert len(c) >= 33
+    assert len(c) >= 50 and "pt_group_reduce" in [f[0] for f in c]
     assert [f[0] for f in rust] == [f[0] for f in c]
-    ret = {"int": "i32", "int64_t": "i64", "void": "()", "const char *": "*const c_char", "void *": "*mut c_void"}
+    ret = {"int": "i32", "int64_t": "i64", "void": "()", "const char *": "*const c_char", "void *": "*mut c_void", "pt_ctx *": "*mut PtCtx"}
     for (name, n, r), (_, rn, rr) in zip(c, rust):
         assert n == rn, f"{name}: {n} parameters in ptrt.h, {rn} in lib.rs"
         assert ret[r] == rr, f"{name}: returns {r} in ptrt.h, {rr} in lib.rs"
@@ -54,5 +54,5 @@ def test_build_rs_carries_the_contract_flags():
                  "-fno-gpu-flush-denormals-to-zero", "-DPT_TRACE_WAVES_PER_EU=5"):
         assert f'"{flag}"' in rs, flag
     assert "--offload-arch=$(ARCH)" in mk and "-ffp-contract=off" in mk
-    for src in ("pt_api.hip", "pt_kernels.hip", "pt_host.cpp"):
+    for src in ("pt_api.hip", "pt_kernels.hip", "pt_group.hip", "pt_host.cpp"):
         assert src in rs and src in mk

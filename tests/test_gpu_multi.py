@@ -49,8 +49,9 @@ def test_two_hip_ranks_sum_to_the_single_rank_image(pt, po, scenes, tmp_path, me
 def test_bench_step_with_the_reduce_path_on_one_rank(tmp_path):
     """bench.py's N > 1 step -- RCCL group, sum-reduce of the device sums, barrier, all-reduces of time and rays -- run
     on this one GPU as a one-rank group (PTRT_BENCH_FORCE_REDUCE=1), beside the plain one-process run of the same
-    steps: same rays, a well-formed line, and a step that is not slower for having RCCL's streams in the process (the
-    sky-only tiles' loop must still run beside the megakernel; 1.08 x when it does not)."""
+    steps: same rays, a well-formed line, and -- the mechanism, not the clock -- the GPU's stream pair still runs side by
+    side with RCCL's streams in the process, so that the sky-only tiles' loop runs beside the megakernel (a step is 1.08 x
+    as long when it does not; the wall-clock bound below is only a coarse guard against that and worse)."""
     import json
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "3", "--no-cpu-baseline"]
     lines = []
@@ -66,4 +67,9 @@ def test_bench_step_with_the_reduce_path_on_one_rank(tmp_path):
     for d in lines:
         assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "Mrays/s" and d["roofline"]["kernel_ms"] > 0
     assert forced["config"]["rays_per_step"] == plain["config"]["rays_per_step"]
-    assert forced["ms_per_step"] < 1.05 * plain["ms_per_step"], (forced["ms_per_step"], plain["ms_per_step"])
+    for d in lines:
+        assert d["config"]["sky_loop_beside"] == 1
+        c = d["config"]
+        assert c["rays_sky_loop"] > 0 and c["rays_walked"] > 0 and c["rays_sky_loop"] + c["rays_megakernel"] + c["rays_walked"] == c["rays_per_step"]
+        assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac"] == d["roofline"]["valu_frac"]
+    assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"], (forced["ms_per_step"], plain["ms_per_step"])

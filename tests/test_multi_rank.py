@@ -26,6 +26,35 @@ def test_frames_for_rank_partitions_the_job(pt):
         multi.frames_for_rank(2, 2, 0, 4)
 
 
+def test_group_entry_points_without_a_gpu(pt):
+    """pt_group_*: argument checks and the failure path on a machine without a GPU (a message, a status, no handle); the
+    frame shares pt_group_render_frames deals are those of frames_for_rank (stated in include/ptrt.h: member g renders
+    time0 + g with stride G)."""
+    import ctypes as C
+    import torch
+    l = pt.lib()
+    out = C.c_void_p(1)
+    devs = (C.c_int * 2)(0, 1)
+    assert l.pt_group_create(None, 2, 64, 64, 0, C.byref(out)) == -1 and not out.value
+    assert l.pt_group_create(devs, 65, 64, 64, 0, C.byref(out)) == -1
+    assert l.pt_group_create(devs, 2, 64, 64, 0x10, C.byref(out)) == -1 and b"flag" in l.pt_group_last_error(None)
+    assert l.pt_group_create(devs, 2, 64, 64, 0, None) == -1
+    if not torch.cuda.is_available():
+        rc = l.pt_group_create(devs, 2, 64, 64, 0, C.byref(out))
+        assert rc == -2 and not out.value and b"member 0" in l.pt_group_last_error(None)
+    for fn in (l.pt_group_sync, l.pt_group_reset):
+        assert fn(None) == -1
+    assert l.pt_group_size(None) == 0 and l.pt_group_member(None, 0) is None
+    l.pt_group_destroy(None)
+    multi = importlib.import_module("path_tracer_amd.multi")
+    text = open(os.path.join(ROOT, "path-tracer_amd", "csrc", "pt_group.hip")).read()
+    assert "pt_render_frames(g->members[m], time0 + m, G, count)" in text and "(n_frames - g + G - 1u) / G" in text
+    for G in (1, 2, 3, 8):
+        for n in (0, 1, 7, 8, 9):
+            for g in range(G):
+                assert multi.frames_for_rank(g, G, 10, n)[2] == ((n - g + G - 1) // G if n > g else 0)
+
+
 def _worker(rank, world, port, n_frames, out_path):
     sys.path.insert(0, ROOT)
     import torch

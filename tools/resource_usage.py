@@ -14,6 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "path-tracer_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+# template instantiations the library launches (launch_items: 2 x 2 x 5; launch_pool: 2 x 5)
+EXPECTED_TRACE_VARIANTS = 20
+EXPECTED_POOL_VARIANTS = 10
+
 FIELDS = {
     "TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch",
     "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
@@ -35,10 +39,21 @@ def demangle(names: list[str]) -> list[str]:
         return names
 
 
-def usage(extra: list[str] | None = None, out_asm: str = "/tmp/pt_kernels_usage.s") -> list[dict]:
+def usage(extra: list[str] | None = None, out_asm: str | None = None) -> list[dict]:
+    """out_asm: where to keep the assembly (default: a temporary file of this call's own, deleted afterwards)."""
+    import tempfile
+    tmp = None
+    if out_asm is None:
+        fd, tmp = tempfile.mkstemp(prefix="pt_kernels_usage_", suffix=".s")
+        os.close(fd)
+        out_asm = tmp
     cmd = [HIPCC] + device_flags() + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                                       os.path.join(CSRC, "pt_kernels.hip"), "-o", out_asm] + (extra or [])
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    finally:
+        if tmp is not None and os.path.exists(tmp):
+            os.unlink(tmp)
     if p.returncode != 0:
         sys.stderr.write(p.stderr)
         raise RuntimeError("hipcc failed")
@@ -61,7 +76,19 @@ def usage(extra: list[str] | None = None, out_asm: str = "/tmp/pt_kernels_usage.
 
 
 def check(kernels: list[dict]) -> None:
-    """The gate: the megakernels (trace_kernel, pool_kernel) keep everything in registers."""
+    """The gate: the megakernels (trace_kernel, pool_kernel) keep everything in registers.  It must not pass by having
+    seen nothing: every variant the library launches has to be in the compiler's report, each with its spill and
+    private-segment fields."""
+    mega = [k for k in kernels if re.search(r"(trace|pool)_kernel", k["pretty"])]
+    n_trace = sum("trace_kernel" in k["pretty"] for k in mega)
+    n_pool = sum("pool_kernel" in k["pretty"] for k in mega)
+    if n_trace < EXPECTED_TRACE_VARIANTS or n_pool < EXPECTED_POOL_VARIANTS:
+        raise RuntimeError(f"the compiler's resource report lists {n_trace} trace_kernel and {n_pool} pool_kernel variants, expected at least "
+                           f"{EXPECTED_TRACE_VARIANTS} and {EXPECTED_POOL_VARIANTS}: has the remark format changed?")
+    for k in mega:
+        missing = [f for f in ("sgpr_spill", "vgpr_spill", "scratch", "vgpr") if f not in k]
+        if missing:
+            raise RuntimeError(f"{k['pretty']}: the resource report lacks {missing}: has the remark format changed?")
     bad = [k for k in kernels if re.search(r"(trace|pool)_kernel", k["pretty"])
            and (k.get("sgpr_spill", 0) or k.get("vgpr_spill", 0) or k.get("scratch", 0))]
     if bad:
