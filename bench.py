@@ -80,6 +80,10 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
     ap.add_argument("--sky-size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group", action="store_true",
+                    help="one process drives all --gpus GPUs through the C ABI's pt_group_* (frames dealt over the GPUs, one "
+                         "pt_group_reduce per step) instead of one torch.distributed rank per GPU")
+    ap.add_argument("--group-rccl", action="store_true", help="with --group: sum with RCCL instead of peer copies in a fixed order")
     return ap.parse_args(argv)
 
 
@@ -140,8 +144,60 @@ def cpu_baseline(pt, scenes, scene, w, h, settings, sky_cube, budget_s: float = 
                       f"oracle/pt_oracle.c, gcc -O2 -ffp-contract=off, pthreads"}
 
 
+def main_group(args):
+    """`--group`: the step of main() with one process and one host thread for all GPUs -- clear, the step's frames dealt
+    over the GPUs by pt_group_render_frames, one pt_group_reduce onto GPU 0 -- timed by the host clock around a
+    pt_group_sync on both sides.  No roofline block (that is the per-rank run's business), same metric."""
+    import numpy as np
+    import _pkgload
+    pt = _pkgload.load()
+    scenes = importlib.import_module("path_tracer_amd.scenes")
+    factory, w, h, settings, frames = scenes.CONFIGS[args.workload]
+    scene = factory()
+    if args.frames:
+        frames = args.frames
+    scaling = args.scaling or DEFAULT_SCALING.get(args.workload, "weak")
+    total = frames * args.gpus if scaling == "weak" else frames
+    g = pt.RendererGroup(scene, w, h, list(range(args.gpus)), settings=settings, group_flags=pt.PT_GROUP_RCCL if args.group_rccl else 0)
+    pano_w = min(4096, max(8, args.sky_size))
+    g.set_sky_equirect(scenes.sky_equirect(pano_w, pano_w // 2), args.sky_size)
+
+    def step(i: int):
+        g.reset_ready_samples()
+        g.render_frames(1 + i * total, total)
+        g.reduce(0)
+
+    for i in range(args.warmup):
+        step(args.steps + i)
+    g.sync()
+    t0 = time.perf_counter()
+    rays = 0
+    for i in range(args.steps):
+        step(i)
+        rays += g.stats()["rays"]  # (reset clears the counters; reading them waits for the step: steps do not overlap)
+    g.sync()
+    elapsed = time.perf_counter() - t0
+    frames_seen = int(g.read_sum(0)[0, 0, 3])
+    out = {
+        "metric": "Mrays/s, bunny 1080p 8-bounce, 1/2/4/8 GPUs; % FP32 VALU peak",
+        "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "width": w, "height": h, "depth": settings.depth,
+                   "spp_per_step": total * settings.samples_per_pixel, "triangles": int(len(scene.triangles)),
+                   "rays_per_step": rays // max(args.steps, 1), "frames_in_reduced_image": frames_seen,
+                   "parallelism": f"pt_group x{args.gpus} ({scaling}), one process, one {'RCCL' if args.group_rccl else 'peer-copy'} reduce per step"},
+        "roofline": None, "cpu_baseline": None,
+    }
+    assert frames_seen == total, (frames_seen, total)
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main():
     args = parse_args()
+    if args.group:
+        return main_group(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Nothing in this process has touched the GPU yet: start the ranks as children and pass their output through.
         cmd = self_launch_command(args, sys.argv[1:], free_port())

@@ -138,8 +138,8 @@ int pt_render(pt_ctx *ctx, uint32_t time);
  * n_frames pt_render calls (every frame is summed on its own and the frames are added in order).
  * Launches of 16 frames or more are split into work items of several frames by measured cost
  * and summed per item: same samples, sums equal up to fp32 summation order, and several times
- * the throughput (1080p bench scene: 0.86 ms for one frame, 0.31 ms per frame in a 15-frame
- * launch, 0.2 ms in a 16-frame one, 0.09 ms from 192 frames on). */
+ * the throughput (1080p bench scene: 0.76 ms for one frame, 0.15 ms per frame in a 15-frame
+ * launch, 0.1 ms in a 16-frame one, 0.05 ms from 256 frames on). */
 int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames);
 /* Device memory pt_render_frames allocates on demand and keeps until pt_destroy (it never shrinks): the work-item
  * table and partial sums of the largest launch so far, 1040 bytes per planned work item -- launches of 16 frames
@@ -148,11 +148,13 @@ int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_fr
  * items as long as that stays below 640 MiB (1080p, 15 frames: 551 MB) and otherwise run frame after frame with no
  * such memory -- and, for BVHs deeper than the kernels' on-chip stacks (24 levels per-tile, 8 pooled), 4 bytes per
  * lane and extra level.  The first call that needs more than the context holds synchronises the stream, frees and
- * allocates.  pt_render_frames_static never allocates. */
-/* No counterpart in the reference.  For callers that cannot allocate device memory while rendering (code under HIP
- * graph capture, serving loops, harnesses that forbid hipMalloc): the same launches as pt_render_frames, bit for
- * bit, but the work-item table, the partial sums and the deep-stack spill space come from a static 192 MiB device
- * array that the library holds once per GPU for the life of the process, and no hipMalloc / hipFree is called.
+ * allocates. */
+/* No counterpart in the reference.  For callers that cannot allocate device memory while rendering (serving loops,
+ * harnesses that forbid hipMalloc): the same launches as pt_render_frames, bit for bit, but the work-item table, the
+ * partial sums and the deep-stack spill space come from a static 192 MiB device array that the library holds once per
+ * GPU for the life of the process, and no hipMalloc / hipFree is called during the call.  (Not exercised under HIP graph
+ * capture: what a call launches depends on host-side state -- the plan's phase, the frame counter, the time values --
+ * which a captured graph would freeze.)
  * A launch that needs more (see above; 1080p: up to about 100 frames per call) is rejected with PT_ERR_LIMIT and
  * nothing is rendered: ask for fewer frames per call.  Not available while a window is set.  All contexts of a GPU
  * share the array: calls that overlap in time on one GPU (different streams or threads) race; calls that follow one

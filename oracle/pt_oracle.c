@@ -422,6 +422,9 @@ static v3 ray_color(ctx_t *cx, ray_t initial, uint32_t st[4], uint32_t depth, ui
     cx->st.paths++;
     for (uint32_t i = 0; i < depth + correction; i++) {
         const hit_t h = hit_scene(cx, cur);
+#ifdef PTO_RAY_HOOK
+        PTO_RAY_HOOK(cx, i);   /* analysis builds only (tests/csrc/walk_stats.c): after every hitScene, with the bounce index */
+#endif
         if (i == 0 && first_prim) { *first_prim = h.hit ? h.prim : 0xFFFFFFFFu; *first_t = h.hit ? h.t : 0.0f; }
         if (!h.hit) { color = vmul(color, sky_lookup(cx, cur.d)); break; }
         cx->st.bounces++;

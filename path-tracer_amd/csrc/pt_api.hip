@@ -226,9 +226,12 @@ struct DeviceGuard {
                         hipGetErrorString(e_));                                                        \
     } while (0)
 
+// (a status left behind by an earlier failed HIP call of anybody in the process would otherwise be reported by this
+// entry point's first launch check: it is dropped on the way in)
 #define PT_ENTER(ctx)                                                 \
     if (!(ctx)) return fail(nullptr, PT_ERR_INVALID, "null context"); \
     DeviceGuard device_guard_;                                        \
+    (void)hipGetLastError();                                          \
     PT_HIP(ctx, hipSetDevice((ctx)->device))
 
 template <typename T>

@@ -294,11 +294,12 @@ void pt_group_destroy(pt_group *g)
         if (c) (void)g_rccl.CommDestroy(c);
     free_staging(g);
     for (size_t m = 0; m < g->members.size(); m++) pt_destroy(g->members[m]);  // (synchronises the member's stream first)
-    for (size_t m = 0; m < g->devices.size(); m++) {
+    for (size_t m = 0; m < g->streams.size(); m++) {  // (only members that came into being: their devices are valid)
         if (hipSetDevice(g->devices[m]) != hipSuccess) continue;
         if (m < g->events.size() && g->events[m]) (void)hipEventDestroy(g->events[m]);
-        if (m < g->streams.size() && g->streams[m]) (void)hipStreamDestroy(g->streams[m]);
+        if (g->streams[m]) (void)hipStreamDestroy(g->streams[m]);
     }
+    (void)hipGetLastError();  // nothing here may leave a stale status behind for the caller's next launch check
     delete g;
 }
 

@@ -2180,13 +2180,22 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     r.o = V3(Q.origins[3 * i], Q.origins[3 * i + 1], Q.origins[3 * i + 2]);
     r.d = V3(Q.dirs[3 * i], Q.dirs[3 * i + 1], Q.dirs[3 * i + 2]);
     Counters cn;
+#ifdef PT_TUNING
+    // (tuning builds: the ray's traversal steps ride in the upper bits of `front`, for tools/step_latency.py)
+    const Closest c = hit_scene<true>(Q.sc, r, stack, cn);
+#else
     const Closest c = hit_scene<false>(Q.sc, r, stack, cn);
+#endif
     const HitRecord h = make_record(Q.sc, r, c);
     if (Q.prim) Q.prim[i] = h.prim;
     if (Q.t) Q.t[i] = h.t;
     if (Q.p) { Q.p[3 * i] = h.p.x; Q.p[3 * i + 1] = h.p.y; Q.p[3 * i + 2] = h.p.z; }
     if (Q.normal) { Q.normal[3 * i] = h.normal.x; Q.normal[3 * i + 1] = h.normal.y; Q.normal[3 * i + 2] = h.normal.z; }
+#ifdef PT_TUNING
+    if (Q.front) Q.front[i] = (h.front ? 1u : 0u) | ((cn.interior + cn.tri_tests) << 1);
+#else
     if (Q.front) Q.front[i] = h.front ? 1u : 0u;
+#endif
 }
 
 // ---- tiles that see nothing but the sky -----------------------------------------------------
