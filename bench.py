@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=0, help="override the configuration's frame count")
     ap.add_argument("--sky-size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rebuild-bvh", action="store_true",
+                    help="PT_FLAG_REBUILD_BVH: walk the library's own binned-SAH tree instead of the reference's (opt-in mode outside "
+                         "the bit-for-bit contract; never the headline number)")
     ap.add_argument("--group", action="store_true",
                     help="one process drives all --gpus GPUs through the C ABI's pt_group_* (frames dealt over the GPUs, one "
                          "pt_group_reduce per step) instead of one torch.distributed rank per GPU")
@@ -239,7 +242,8 @@ def main():
     # the renderer accumulates straight into a torch tensor so RCCL can reduce it in place
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    r = pt.Renderer(scene, w, h, device=local_rank, settings=settings, stream=stream.cuda_stream)
+    base_flags = pt.PT_FLAG_REBUILD_BVH if args.rebuild_bvh else 0
+    r = pt.Renderer(scene, w, h, device=local_rank, settings=settings, stream=stream.cuda_stream, flags=base_flags)
     r.bind_accum(accum.data_ptr())
     pano_w = min(4096, max(8, args.sky_size))
     pano = scenes.sky_equirect(pano_w, pano_w // 2)
@@ -291,7 +295,7 @@ def main():
     sky_px = sky_loop_pixels(r.read_sky_tiles(), w, h)
     launches = [frames_of_step(multi, rank, world, scaling, frames, i) for i in range(args.steps)]
     sky_rays = sum(sky_px * l[2] * spp for l in launches)
-    r.set_flags(pt.PT_FLAG_DETAILED_STATS)
+    r.set_flags(pt.PT_FLAG_DETAILED_STATS | base_flags)
     r.reset_ready_samples()
     st, walked = None, 0
     for l in launches:
@@ -300,7 +304,7 @@ def main():
         if st is None:
             st = dict(cum)
         walked = cum["walks"]
-    r.set_flags(0)
+    r.set_flags(base_flags)
     kinds = torch.tensor([float(sky_rays), float(walked)], dtype=torch.float64, device=dev)
     if reduce_steps:
         dist.all_reduce(kinds, op=dist.ReduceOp.SUM)
@@ -361,7 +365,7 @@ def main():
                        # without any intersection test; handled by the megakernel and ended at its sphere loop + root-box test;
                        # handled by the megakernel and walked through the BVH
                        "rays_sky_loop": sky_step, "rays_megakernel": rays_step - sky_step - walked_step, "rays_walked": walked_step,
-                       "sky_loop_beside": st["sky_loop_beside"],
+                       "sky_loop_beside": st["sky_loop_beside"], "bvh": "library's binned SAH (PT_FLAG_REBUILD_BVH)" if args.rebuild_bvh else "reference (bvh.rs midpoint split)",
                        "parallelism": f"sample-split x{world} ({scaling}), one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": roof,
         }

@@ -13,7 +13,7 @@ fn main() {
         .map(PathBuf::from)
         .unwrap_or_else(|_| manifest.join("../../path-tracer_amd/csrc"));
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".to_string());
-    let sources = ["pt_api.hip", "pt_kernels.hip", "pt_group.hip", "pt_host.cpp"];
+    let sources = ["pt_api.hip", "pt_kernels.hip", "pt_group.hip", "pt_host.cpp", "pt_bvh_sah.cpp"];
     let headers = ["pt_kernels.h", "pt_layout.h", "pt_math.h", "../../include/ptrt.h"];
     for f in sources.iter().chain(headers.iter()) {
         println!("cargo:rerun-if-changed={}", src.join(f).display());

@@ -47,6 +47,7 @@ pub const PT_FLAG_TILE_KERNEL: u32 = 8;
 pub const PT_FLAG_POOL_KERNEL: u32 = 16;
 pub const PT_FLAG_TRIANGLE_MATERIALS: u32 = 32;
 pub const PT_FLAG_REGROUP_SHORT: u32 = 64;
+pub const PT_FLAG_REBUILD_BVH: u32 = 128;
 pub const PT_GROUP_RCCL: u32 = 1;
 pub const PT_PRIM_NONE: u32 = 0xFFFF_FFFF;
 pub const PT_PRIM_SPHERE: u32 = 0x8000_0000;
@@ -99,6 +100,7 @@ extern "C" {
     pub fn pt_group_sync(g: *mut PtGroup) -> i32;
     pub fn pt_group_stats(g: *mut PtGroup, out: *mut PtStats) -> i32;
     pub fn pt_bvh_build(tris: *const c_void, n_tris: u32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
+    pub fn pt_bvh_build_sah(tris: *const c_void, n_tris: u32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
     pub fn pt_plane_triangles(q: *const f32, u: *const f32, v: *const f32, albedo: *const f32, material: u32, tris_out: *mut c_void) -> i32;
     pub fn pt_pack_spheres(spheres8: *const f32, n: u32, sphere_data8208_out: *mut c_void) -> i32;
     pub fn pt_obj_load(path: *const c_char, tris_out: *mut c_void, capacity: u32, n_tris: *mut u32) -> i32;

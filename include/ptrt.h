@@ -66,6 +66,12 @@ typedef enum pt_status {
  * display frame and want them sooner: 8 frames of the 69 k-triangle 1080p scene 1.9 -> 1.2 ms, 15 frames 2.8 -> 1.7.
  * No counterpart in the reference, which renders one frame per dispatch. */
 #define PT_FLAG_REGROUP_SHORT 64u
+/* Off by default, and outside the bit-for-bit contract with the reference: pt_set_mesh (called while the flag is set)
+ * ignores the caller's nodes and index permutation and walks a tree of its own over the same triangles
+ * (pt_bvh_build_sah).  Primary-hit ids, t and radiance then agree with the reference tree's except on the ambiguous
+ * cases named at pt_bvh_build_sah (none in 2 million primary rays of the 69 k-triangle scene; the converged images agree
+ * far below 1e-3 RMSE), for about a third fewer traversal steps.  No counterpart in the reference. */
+#define PT_FLAG_REBUILD_BVH 128u
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */
 #define PT_PRIM_NONE 0xFFFFFFFFu      /* miss */
@@ -256,6 +262,14 @@ int pt_group_stats(pt_group *g, pt_stats_t *out);
  * nodes_out holds 2*n_tris-1 records of 32 B, idx_out n_tris u32.  Returns nodes used,
  * 0 for an empty mesh, negative pt_status on bad arguments. */
 int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out);
+/* No counterpart in the reference: another tree over the same triangles in the same node format -- binned surface-area
+ * heuristic instead of the reference's midpoint split (bvh.rs:101-124), leaves of up to four triangles.  Same buffers and
+ * return value as pt_bvh_build.  A traversal of it visits about two thirds of the nodes and triangles (69 k-triangle
+ * scene: 22.5 instead of 34.3 steps per ray that enters the tree) and returns the same closest hit except where the
+ * shader's arithmetic is itself ambiguous: two triangles at exactly the same t (the first one tested wins,
+ * compute.wgsl:286-290, and the order of tests is the tree's) and rays grazing a node's box, where the float slab test
+ * (compute.wgsl:441-456) and the triangle test disagree.  What PT_FLAG_REBUILD_BVH uses. */
+int64_t pt_bvh_build_sah(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out);
 /* Plane::triangles (src/scene/plane.rs:16-41): writes two 112-byte records. */
 int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3],
                        uint32_t material, void *tris_out);

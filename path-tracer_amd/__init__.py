@@ -30,6 +30,7 @@ PT_FLAG_TILE_KERNEL = 8
 PT_FLAG_POOL_KERNEL = 16
 PT_FLAG_TRIANGLE_MATERIALS = 32
 PT_FLAG_REGROUP_SHORT = 64
+PT_FLAG_REBUILD_BVH = 128
 PT_GROUP_RCCL = 1
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
@@ -125,6 +126,7 @@ ABI = [
     ("pt_group_sync", _I, [_VP]),
     ("pt_group_stats", _I, [_VP, C.POINTER(Stats)]),
     ("pt_bvh_build", C.c_int64, [_VP, _U32, _VP, _VP]),
+    ("pt_bvh_build_sah", C.c_int64, [_VP, _U32, _VP, _VP]),
     ("pt_plane_triangles", _I, [_VP, _VP, _VP, _VP, _U32, _VP]),
     ("pt_pack_spheres", _I, [_VP, _U32, _VP]),
     ("pt_obj_load", _I, [C.c_char_p, _VP, _U32, C.POINTER(_U32)]),
@@ -255,6 +257,21 @@ def bvh_build(triangles: np.ndarray):
     idx = np.zeros(n, np.uint32)
     used = lib().pt_bvh_build(_ptr(triangles), n, _ptr(nodes), _ptr(idx))
     _host_check(used)
+    return nodes[:used].copy(), idx
+
+
+def bvh_build_sah(triangles: np.ndarray):
+    """pt_bvh_build_sah: a binned-SAH tree in the reference's node format -> (nodes, triangle_indices).  Not the
+    reference's tree: what PT_FLAG_REBUILD_BVH walks (opt-in, outside the bit-for-bit contract)."""
+    triangles = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+    n = len(triangles)
+    if n == 0:
+        return np.zeros(0, NODE_DTYPE), np.zeros(0, np.uint32)
+    nodes = np.zeros(2 * n - 1, NODE_DTYPE)
+    idx = np.zeros(n, np.uint32)
+    used = lib().pt_bvh_build_sah(_ptr(triangles), n, _ptr(nodes), _ptr(idx))
+    if used < 0:
+        raise PtError(int(used), "pt_bvh_build_sah failed")
     return nodes[:used].copy(), idx
 
 

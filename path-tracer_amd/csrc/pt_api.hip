@@ -516,7 +516,7 @@ static int pt_set_flags_impl(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS | PT_FLAG_REGROUP_SHORT)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS | PT_FLAG_REGROUP_SHORT | PT_FLAG_REBUILD_BVH)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
@@ -531,14 +531,27 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
         return PT_OK;
     }
     if (!tris_v || !nodes_v || !tri_idx || n_tris == 0 || n_idx == 0) return fail(ctx, PT_ERR_INVALID, "pt_set_mesh: null or empty input with n_nodes=%u", n_nodes);
+    const PtTriangle *tris = static_cast<const PtTriangle *>(tris_v);
+    const PtNode *nodes = static_cast<const PtNode *>(nodes_v);
+    // PT_FLAG_REBUILD_BVH: the library's own tree over the caller's triangles instead of the caller's (the reference's)
+    std::vector<PtNode> own_nodes;
+    std::vector<uint32_t> own_idx;
+    if (ctx->flags & PT_FLAG_REBUILD_BVH) {
+        own_nodes.resize(2 * (size_t)n_tris - 1);
+        own_idx.resize(n_tris);
+        const int64_t used = pt_bvh_build_sah(tris_v, n_tris, own_nodes.data(), own_idx.data());
+        if (used <= 0) return fail(ctx, used == PT_ERR_NOMEM ? PT_ERR_NOMEM : PT_ERR_INVALID, "pt_set_mesh: PT_FLAG_REBUILD_BVH: the tree could not be built");
+        nodes = own_nodes.data();
+        n_nodes = (uint32_t)used;
+        tri_idx = own_idx.data();
+        n_idx = n_tris;
+    }
     // Walk table: node pairs (32 bytes per node, stored one node late) and, from the next 64-byte boundary on, one
     // 64-byte record per triangle slot; positions are 32-byte units counted from the array's second unit.
     const uint64_t tri_first_unit = ((uint64_t)n_nodes + 2) & ~1ull;  // even: 64-byte aligned
     const uint64_t table_units = tri_first_unit + 2 * (uint64_t)n_idx;
     if (table_units > (1ull << 27)) return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: %u nodes and %u triangle slots need a walk table of more than 4 GiB", n_nodes, n_idx);
     const uint32_t tri_base = (uint32_t)tri_first_unit - 1u;
-    const PtTriangle *tris = static_cast<const PtTriangle *>(tris_v);
-    const PtNode *nodes = static_cast<const PtNode *>(nodes_v);
 
     // Validate, and find the deepest reachable node.  Children must be stored after their
     // parent (the reference's builder guarantees it, bvh.rs:131-134), which rules out cycles.

@@ -2,6 +2,7 @@
 // mutated and truncated Radiance .hdr files, mutated OBJ text, triangle sets with NaN, infinities, duplicates and
 // degenerate extents for the BVH builder (one thread against several).  Prints "ok" when every case ran.
 #include "../../path-tracer_amd/csrc/pt_host.cpp"
+#include "../../path-tracer_amd/csrc/pt_bvh_sah.cpp"
 
 #include <cstdio>
 #include <random>
@@ -120,6 +121,21 @@ int main()
         if (u1 <= 0 || u1 != u4 || std::memcmp(n1.data(), n4.data(), (size_t)u1 * sizeof(PtNode)) != 0 || i1 != i4) {
             std::printf("bvh round %d: thread counts disagree (%lld vs %lld nodes)\n", round, (long long)u1, (long long)u4);
             return 3;
+        }
+        // the other builder on the same hostile triangles: in bounds, a permutation, children behind their parent
+        std::vector<PtNode> ns(2 * (size_t)n - 1);
+        std::vector<uint32_t> is(n);
+        const int64_t us = pt_bvh_build_sah(tris.data(), n, ns.data(), is.data());
+        std::vector<char> seen(n, 0);
+        bool good = us >= 1 && us <= 2 * (int64_t)n - 1;
+        for (uint32_t k = 0; good && k < n; k++) { good = is[k] < n && !seen[is[k]]; if (good) seen[is[k]] = 1; }
+        for (int64_t k = 0; good && k < us; k++) {
+            if (ns[k].triangle_count == 0) good = ns[k].left_child_index > k && (int64_t)ns[k].left_child_index + 1 < us;
+            else good = (uint64_t)ns[k].left_child_index + ns[k].triangle_count <= n;
+        }
+        if (!good) {
+            std::printf("bvh round %d: the SAH builder's tree is malformed (%lld nodes)\n", round, (long long)us);
+            return 4;
         }
     }
     std::printf("bvh: thread counts agree\nok\n");

@@ -300,3 +300,58 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(root, "include"),
                            str(src), "-o", str(exe), "-L", lib_dir, "-lptrt", "-Wl,-rpath," + lib_dir])
     subprocess.check_call(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", header])
+
+
+def _check_tree(pt, tris, nodes, idx, max_leaf):
+    """Invariants of a tree in the reference's node format: a permutation of the triangles, children adjacent and behind
+    their parent, every leaf's and every interior node's box around what is below it."""
+    n = len(tris)
+    assert sorted(idx.tolist()) == list(range(n))
+    assert 1 <= len(nodes) <= max(2 * n - 1, 1)
+    lo = np.minimum(np.minimum(tris["a"], tris["b"]), tris["c"])
+    hi = np.maximum(np.maximum(tris["a"], tris["b"]), tris["c"])
+    seen = np.zeros(n, bool)
+    todo = [0]
+    visited = 0
+    while todo:
+        i = todo.pop()
+        visited += 1
+        nd = nodes[i]
+        if nd["count"] == 0:
+            l = int(nd["left"])
+            assert i < l and l + 1 < len(nodes)
+            for c in (l, l + 1):
+                assert (nodes[c]["min"] >= nd["min"]).all() and (nodes[c]["max"] <= nd["max"]).all()
+            todo += [l + 1, l]
+        else:
+            assert nd["count"] <= max_leaf
+            t = idx[int(nd["left"]):int(nd["left"]) + int(nd["count"])]
+            assert not seen[t].any()
+            seen[t] = True
+            assert (lo[t] >= nd["min"]).all() and (hi[t] <= nd["max"]).all()
+    assert seen.all() and visited == len(nodes)
+
+
+def test_sah_builder_invariants_and_same_hits_as_the_reference_tree(pt, po, scenes):
+    """pt_bvh_build_sah (what PT_FLAG_REBUILD_BVH walks): a valid tree in the reference's node format over the same
+    triangles, with fewer traversal steps, and -- traversed by the oracle's hitScene -- the same closest hits as the
+    reference's tree on rays without ties."""
+    for tris in (scenes.blob_mesh(10), scenes.cornell().triangles, scenes.blob_mesh(3)[:1], scenes.blob_mesh(3)[:3],
+                 np.repeat(scenes.blob_mesh(3)[:1], 9)):                      # (nine copies of one triangle: no split separates them)
+        nodes, idx = pt.bvh_build_sah(tris)
+        _check_tree(pt, tris, nodes, idx, 4)
+    scene = scenes.bunny(n=14)
+    nodes, idx = pt.bvh_build_sah(scene.triangles)
+    _check_tree(pt, scene.triangles, nodes, idx, 4)
+    st = pt.Settings(1, 6, 1e-4, 1000.0)
+    w, h = 160, 96
+    ref = po.from_scene(scene, w, h, st, None)
+    sah = po.OracleScene(w, h, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), scene.triangles, nodes, idx, None, 0)
+    a, prim_a, t_a, sa = ref.render(3, want_aov=True)
+    b, prim_b, t_b, sb = sah.render(3, want_aov=True)
+    assert np.array_equal(prim_a, prim_b) and np.array_equal(t_a.view(np.uint32), t_b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa["rays"] == sb["rays"]
+    steps = lambda s: s["interior"] + s["tri_tests"] - s["rays"]        # (every ray's root visit taken out)
+    assert steps(sb) < 0.8 * steps(sa), (steps(sa), steps(sb))
+    assert pt.lib().pt_bvh_build_sah(None, 3, None, None) == -1
+    assert pt.lib().pt_bvh_build_sah(None, 0, None, None) == 0
