@@ -178,3 +178,21 @@ def test_field_planned_launch_matches_oracle(pt, po, scenes, field):
     assert r.stats()["rays"] == rays and (got[..., 3] == n).all()
     np.testing.assert_allclose(got, want, rtol=n * 2.0 ** -23, atol=1e-6)
     r.close()
+
+
+@pytest.mark.library_choice
+def test_bench_sky_cube_4096_matches_oracle(pt, po, scenes):
+    """The benchmark's own sky: the 4096 x 2048 procedural panorama through equirect_kernel into the 4096^2 cube
+    (shaders/equirectangular.wgsl:12-81, renderer.rs:218), every texel of every face against the oracle's
+    pto_equirect_to_cube, bit for bit -- and every 64th row once more on its own, so that a failure names the face and row."""
+    pano = scenes.sky_equirect(4096, 2048)
+    r = pt.Renderer(scenes.three_balls(), 64, 40, settings=pt.Settings(1, 2, 1e-4, 1000.0))
+    r.set_sky_equirect(pano, 4096)
+    got = r.read_sky_cube()
+    r.close()
+    want = po.equirect_to_cube(pano, 4096)
+    assert got.shape == want.shape == (6, 4096, 4096, 4)
+    for face in range(6):
+        for row in range(0, 4096, 64):
+            assert np.array_equal(got[face, row].view(np.uint32), want[face, row].view(np.uint32)), f"face {face}, row {row}"
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

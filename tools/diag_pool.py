@@ -68,7 +68,12 @@ if m[3] > 0:
     print("hit passes %.1f%% of passes: %.1f lanes, %.0f cycles; miss passes: %.1f lanes, %.0f cycles" % (
         100 * hp / ap, hl / max(hp, 1), hc / max(hp, 1), (al - hl) / max(ap - hp, 1), (ac - hc) / max(ap - hp, 1)))
     nm = max(ap - hp, 1)
-    names = ["pop", "state load", "sky issue + new path", "spheres + root visit", "hand-over stores", "sky wait + sums", "write-back + jobs + pushes"]
+    # (the kernel's stamps dg_sec[0..6] in miss_pass: ring pop; slot state from LDS; sky texel asked for + frame counters + RNG
+    # and camera ray; walk_begin_pool of the new ray; everything up to the end of the round's lane work -- the retired
+    # path's sums, a sphere hit shaded in place with its bounce ray's own walk_begin_pool, and the hand-over stores of
+    # lanes that leave the loop; the wait for loads still outstanding at the round's end; after the loop)
+    names = ["pop", "state load", "sky issue + new path", "spheres + root visit", "sums + sphere hit shaded in place (with the bounce ray's spheres + root visit) + hand-over stores",
+             "wait for outstanding loads", "write-back + jobs + pushes"]
     print("miss pass rounds per pass %.2f, lanes per round %.1f" % (m[6] / nm, m[7] / max(m[6], 1)))
     print("after a miss pass: job hand-out %.0f cycles per pass (%.1f lanes finished their job), ring pushes %.0f" % (extra[0] / nm, extra[2] / nm, extra[1] / nm))
     print("miss pass sections (cycles): " + ", ".join(f"{n} {v / nm:.0f}" for n, v in zip(names, sec)))
