@@ -98,12 +98,27 @@ def check(kernels: list[dict]) -> None:
                            "compiler's lane-spill code has failed before):\n" + lines)
 
 
+def table(ks: list[dict]) -> str:
+    lines = [f"{'kernel':<58}{'sgpr':>5}{'vgpr':>5}{'agpr':>5}{'sspill':>7}{'vspill':>7}{'scratch':>8}{'lds':>7}{'occ':>4}"]
+    for k in ks:
+        name = k["pretty"] if len(k["pretty"]) < 58 else k["pretty"].split("(")[0]
+        lines.append(f"{name:<58}{k.get('sgpr', 0):>5}{k.get('vgpr', 0):>5}{k.get('agpr', 0):>5}{k.get('sgpr_spill', 0):>7}"
+                     f"{k.get('vgpr_spill', 0):>7}{k.get('scratch', 0):>8}{k.get('lds', 0):>7}{k.get('occupancy', 0):>4}")
+    return "\n".join(lines) + "\n"
+
+
+def write_record(ks: list[dict], path: str) -> None:
+    """The table of the build at hand, kept under profiles/ (the build step rewrites it, so it cannot go stale)."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("# registers, spills, private segment, LDS and occupancy of every kernel of pt_kernels.hip as hipcc reports them for\n"
+                "# gfx950 with the library's flags (tools/resource_usage.py; rewritten by __graft_entry__.build())\n")
+        f.write(table(ks))
+
+
 def main():
     ks = usage(sys.argv[1:])
-    print(f"{'kernel':<58}{'sgpr':>5}{'vgpr':>5}{'agpr':>5}{'sspill':>7}{'vspill':>7}{'scratch':>8}{'lds':>7}{'occ':>4}")
-    for k in ks:
-        print(f"{k['pretty']:<58}{k.get('sgpr', 0):>5}{k.get('vgpr', 0):>5}{k.get('agpr', 0):>5}{k.get('sgpr_spill', 0):>7}"
-              f"{k.get('vgpr_spill', 0):>7}{k.get('scratch', 0):>8}{k.get('lds', 0):>7}{k.get('occupancy', 0):>4}")
+    sys.stdout.write(table(ks))
     try:
         check(ks)
     except RuntimeError as e:
