@@ -108,8 +108,8 @@ def frames_of_step(multi, rank: int, world: int, scaling: str, frames: int, step
     return multi.frames_for_rank(rank, world, 1 + step * total, total)
 
 
-def find_traffic(workload: str, frames_per_launch: int):
-    """HBM bytes per launch from the newest committed PMC record of this workload and launch length
+def find_traffic(workload: str, frames_per_launch: int, bvh: str = "reference"):
+    """HBM bytes per launch from the newest committed PMC record of this workload, launch length and tree
     (profiles/rNN/<anything>/pmc_traffic.json, written by tools/summarize_prof.py)."""
     best = None
     for path in glob.glob(os.path.join(ROOT, "profiles", "**", "pmc_traffic.json"), recursive=True):
@@ -117,7 +117,7 @@ def find_traffic(workload: str, frames_per_launch: int):
             rec = json.load(open(path))
         except Exception:
             continue
-        if rec.get("workload") != workload or rec.get("frames") != frames_per_launch:
+        if rec.get("workload") != workload or rec.get("frames") != frames_per_launch or rec.get("bvh", "reference") != bvh:
             continue
         m = re.search(r"profiles/r(\d+)/", path.replace(os.sep, "/"))
         key = (int(m.group(1)) if m else 0, os.path.getmtime(path))
@@ -317,7 +317,7 @@ def main():
         k_s = k_ms * 1e-3
         valu_tflops = flops / k_s / 1e12
         valu_frac = valu_tflops / FP32_VALU_PEAK_TFLOPS
-        traffic, traffic_src = find_traffic(args.workload, launch[2])
+        traffic, traffic_src = find_traffic(args.workload, launch[2], "sah" if args.rebuild_bvh else "reference")
         fabric_gbs = traffic / k_s / 1e9 if traffic else None
         fabric_frac = fabric_gbs / HBM_PEAK_GBS if traffic else None
         # Which roof: where the walk's working set lives.  Nodes + triangles + normals below the Infinity Cache's size are
