@@ -33,6 +33,15 @@ for k in order[:6]:
 top = order[:64]
 _, _, _, _, ft = r.trace_rays(o[top], d[top])
 launches.append({"what": "the 64 longest, one wave", "rays": 64, "steps_max": int((ft >> 1).max()), "steps_mean": float((ft >> 1).mean())})
+# k long rays per wave, the wave's other lanes given rays that end at once (pointing away from everything)
+away_o, away_d = np.array(cam.origin, np.float32), np.array([0.0, 1.0, 0.3], np.float32)
+for k in (2, 4, 8, 16, 32):
+    oo, dd = np.tile(away_o, (64 * (64 // k), 1)), np.tile(away_d, (64 * (64 // k), 1))
+    for wv in range(64 // k):
+        oo[64 * wv:64 * wv + k] = o[top[wv * k:(wv + 1) * k]]
+        dd[64 * wv:64 * wv + k] = d[top[wv * k:(wv + 1) * k]]
+    _, _, _, _, fk = r.trace_rays(oo, dd)
+    launches.append({"what": f"the 64 longest, {k} per wave ({64 // k} waves)", "rays": len(oo), "steps_max": int((fk >> 1).max()), "steps_mean": float((fk >> 1)[(fk >> 1) > 1].mean())})
 mid = order[2000:2064]
 _, _, _, _, fm = r.trace_rays(o[mid], d[mid])
 launches.append({"what": "64 middling rays, one wave", "rays": 64, "steps_max": int((fm >> 1).max()), "steps_mean": float((fm >> 1).mean())})
