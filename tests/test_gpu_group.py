@@ -112,3 +112,23 @@ def test_group_argument_errors(pt, scenes):
         g.reduce(2)
     assert l.pt_group_member(g._g, 2) is None and l.pt_group_member(g._g, -1) is None
     g.close()
+
+
+@pytest.mark.library_choice
+def test_bench_group_mode_on_one_gpu(tmp_path):
+    """`bench.py --gpus 1 --group`: the bench step through pt_group_* in one process (a one-member group: the reduce is a
+    no-op, everything else is the path an 8-GPU run takes) gives a well-formed line with the same ray count per step as the
+    plain run's frames."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("PTRT_KERNEL", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--group", "--steps", "2", "--warmup", "1", "--frames", "32",
+                          "--sky-size", "256"], env=env, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["unit"] == "Mrays/s" and d["value"] > 0 and d["config"]["frames_in_reduced_image"] == 32
+    assert "pt_group" in d["config"]["parallelism"]
