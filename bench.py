@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--rebuild-bvh", action="store_true",
                     help="PT_FLAG_REBUILD_BVH: walk the library's own binned-SAH tree instead of the reference's (opt-in mode outside "
                          "the bit-for-bit contract; never the headline number)")
+    ap.add_argument("--reference-walk", action="store_true",
+                    help="PT_FLAG_REFERENCE_WALK: the pooled kernel walks the reference tree only (same results bit for bit; measures "
+                         "what the library's second tree is worth)")
     ap.add_argument("--group", action="store_true",
                     help="one process drives all --gpus GPUs through the C ABI's pt_group_* (frames dealt over the GPUs, one "
                          "pt_group_reduce per step) instead of one torch.distributed rank per GPU")
@@ -242,7 +245,7 @@ def main():
     # the renderer accumulates straight into a torch tensor so RCCL can reduce it in place
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    base_flags = pt.PT_FLAG_REBUILD_BVH if args.rebuild_bvh else 0
+    base_flags = (pt.PT_FLAG_REBUILD_BVH if args.rebuild_bvh else 0) | (pt.PT_FLAG_REFERENCE_WALK if args.reference_walk else 0)
     r = pt.Renderer(scene, w, h, device=local_rank, settings=settings, stream=stream.cuda_stream, flags=base_flags)
     r.bind_accum(accum.data_ptr())
     pano_w = min(4096, max(8, args.sky_size))
@@ -278,6 +281,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rays = r.stats()["rays"] - rays_before
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    timed_stats = r.stats()  # (cumulative over warm-up and timed steps)
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rr = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
@@ -365,6 +369,11 @@ def main():
                        # without any intersection test; handled by the megakernel and ended at its sphere loop + root-box test;
                        # handled by the megakernel and walked through the BVH
                        "rays_sky_loop": sky_step, "rays_megakernel": rays_step - sky_step - walked_step, "rays_walked": walked_step,
+                       # the library's second tree (bit-identical results): of all rays rendered so far, those that walked it, and
+                       # of their hits those that failed the check and walked the reference tree as well
+                       "second_tree_nodes": timed_stats["guard_nodes"],
+                       "second_tree_walk_share": timed_stats["guarded"] / max(timed_stats["rays"], 1),
+                       "second_tree_rewalk_share": timed_stats["rewalks"] / max(timed_stats["guarded"], 1),
                        "sky_loop_beside": st["sky_loop_beside"], "bvh": "library's binned SAH (PT_FLAG_REBUILD_BVH)" if args.rebuild_bvh else "reference (bvh.rs midpoint split)",
                        "parallelism": f"sample-split x{world} ({scaling}), one RCCL sum-reduce per step" if world > 1 else "single GPU"},
             "roofline": roof,

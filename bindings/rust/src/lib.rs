@@ -38,6 +38,9 @@ pub struct PtStats {
     pub bvh_depth: u64,
     pub walks: u64,
     pub sky_loop_beside: u64,
+    pub guarded: u64,
+    pub rewalks: u64,
+    pub guard_nodes: u64,
 }
 
 pub const PT_FLAG_REFERENCE_DISPATCH: u32 = 1;
@@ -48,6 +51,7 @@ pub const PT_FLAG_POOL_KERNEL: u32 = 16;
 pub const PT_FLAG_TRIANGLE_MATERIALS: u32 = 32;
 pub const PT_FLAG_REGROUP_SHORT: u32 = 64;
 pub const PT_FLAG_REBUILD_BVH: u32 = 128;
+pub const PT_FLAG_REFERENCE_WALK: u32 = 256;
 pub const PT_GROUP_RCCL: u32 = 1;
 pub const PT_PRIM_NONE: u32 = 0xFFFF_FFFF;
 pub const PT_PRIM_SPHERE: u32 = 0x8000_0000;
@@ -82,6 +86,7 @@ extern "C" {
     pub fn pt_accum_device_ptr(ctx: *mut PtCtx) -> *mut c_void;
     pub fn pt_bind_accum(ctx: *mut PtCtx, device_ptr: *mut c_void) -> i32;
     pub fn pt_trace_rays(ctx: *mut PtCtx, origins: *const f32, dirs: *const f32, n: u32, prim: *mut u32, t: *mut f32, p: *mut f32, normal: *mut f32, front: *mut u32) -> i32;
+    pub fn pt_trace_rays_walked(ctx: *mut PtCtx, origins: *const f32, dirs: *const f32, n: u32, prim: *mut u32, t: *mut f32, p: *mut f32, normal: *mut f32, front: *mut u32, walked: *mut u32) -> i32;
     pub fn pt_group_create(devices: *const i32, n: i32, width: u32, height: u32, flags: u32, out: *mut *mut PtGroup) -> i32;
     pub fn pt_group_destroy(g: *mut PtGroup);
     pub fn pt_group_last_error(g: *const PtGroup) -> *const c_char;
@@ -101,6 +106,7 @@ extern "C" {
     pub fn pt_group_stats(g: *mut PtGroup, out: *mut PtStats) -> i32;
     pub fn pt_bvh_build(tris: *const c_void, n_tris: u32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
     pub fn pt_bvh_build_sah(tris: *const c_void, n_tris: u32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
+    pub fn pt_bvh_build_sah_padded(tris: *const c_void, n_tris: u32, pad: *const f32, nodes_out: *mut c_void, idx_out: *mut u32) -> i64;
     pub fn pt_plane_triangles(q: *const f32, u: *const f32, v: *const f32, albedo: *const f32, material: u32, tris_out: *mut c_void) -> i32;
     pub fn pt_pack_spheres(spheres8: *const f32, n: u32, sphere_data8208_out: *mut c_void) -> i32;
     pub fn pt_obj_load(path: *const c_char, tris_out: *mut c_void, capacity: u32, n_tris: *mut u32) -> i32;

@@ -72,6 +72,13 @@ typedef enum pt_status {
  * cases named at pt_bvh_build_sah (none in 2 million primary rays of the 69 k-triangle scene; the converged images agree
  * far below 1e-3 RMSE), for about a third fewer traversal steps.  No counterpart in the reference. */
 #define PT_FLAG_REBUILD_BVH 128u
+/* Off by default: the pooled kernel walks the caller's tree only.  By default pt_set_mesh (for meshes of 128 triangles
+ * or more whose triangles are small against the mesh) also builds a tree of its own, laid out so that a walk of it
+ * cannot lose a hit, and every triangle hit found on it is checked to be the one a walk of the caller's tree returns;
+ * a ray that fails the check, or starts too far from the mesh, walks the caller's tree.  Results are bit for bit the
+ * same either way (the per-tile kernel, pt_trace_rays and PT_FLAG_DETAILED_STATS always walk the caller's tree); the
+ * flag is there to measure the difference and to save the second tree's memory (about as much again as the first). */
+#define PT_FLAG_REFERENCE_WALK 256u
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */
 #define PT_PRIM_NONE 0xFFFFFFFFu      /* miss */
@@ -94,6 +101,9 @@ typedef struct pt_stats_t {
     uint64_t sky_loop_beside; /* 1: this GPU's stream pair was found to run side by side when it was created, so planned
                                launches run the loop over sky-only tiles beside the megakernel; 0: behind it, on the
                                context's stream (same results, a few per cent slower) */
+    uint64_t guarded;       /* rays that set out on the library's own tree instead of the caller's (see PT_FLAG_REFERENCE_WALK) */
+    uint64_t rewalks;       /* of their hits, those that failed the check and walked the caller's tree as well */
+    uint64_t guard_nodes;   /* nodes of that tree (0: none was built for this mesh) */
 } pt_stats_t;
 
 /* ---- lifetime: Renderer::new / drop (src/renderer.rs:32-37) ------------------------ */
@@ -209,6 +219,12 @@ int pt_bind_accum(pt_ctx *ctx, void *device_ptr);
  * p n x 3, normal n x 3, front n x u32. */
 int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim,
                   float *t, float *p, float *normal, uint32_t *front);
+/* The same, and per ray which tree answered (walked, n x u32, may be NULL): 0 the caller's tree alone, 1 the library's
+ * own tree (see PT_FLAG_REFERENCE_WALK) with its hit taken, 2 that tree first and, its hit failing the check, the
+ * caller's tree after it.  The other outputs are identical in all three cases; this one is a diagnostic and the handle by
+ * which tests aim rays at the scheme's corner cases (edges, vertices, grazing angles).  No counterpart in the reference. */
+int pt_trace_rays_walked(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim,
+                         float *t, float *p, float *normal, uint32_t *front, uint32_t *walked);
 
 /* ---- several GPUs of one node behind one handle ------------------------------------- */
 /* No counterpart in the reference, which drives one GPU.  Frames are independent given their `time` value
@@ -270,6 +286,10 @@ int64_t pt_bvh_build(const void *tris, uint32_t n_tris, void *nodes_out, uint32_
  * compute.wgsl:286-290, and the order of tests is the tree's) and rays grazing a node's box, where the float slab test
  * (compute.wgsl:441-456) and the triangle test disagree.  What PT_FLAG_REBUILD_BVH uses. */
 int64_t pt_bvh_build_sah(const void *tris, uint32_t n_tris, void *nodes_out, uint32_t *idx_out);
+/* The same builder over triangle bounds grown by pad[t] >= 0 on every side (n_tris floats): every box of the result
+ * contains its triangles with at least that much room.  What pt_set_mesh builds its own tree with (see
+ * PT_FLAG_REFERENCE_WALK); exported for tests.  No counterpart in the reference. */
+int64_t pt_bvh_build_sah_padded(const void *tris, uint32_t n_tris, const float *pad, void *nodes_out, uint32_t *idx_out);
 /* Plane::triangles (src/scene/plane.rs:16-41): writes two 112-byte records. */
 int pt_plane_triangles(const float q[3], const float u[3], const float v[3], const float albedo[3],
                        uint32_t material, void *tris_out);

@@ -31,6 +31,7 @@ PT_FLAG_POOL_KERNEL = 16
 PT_FLAG_TRIANGLE_MATERIALS = 32
 PT_FLAG_REGROUP_SHORT = 64
 PT_FLAG_REBUILD_BVH = 128
+PT_FLAG_REFERENCE_WALK = 256
 PT_GROUP_RCCL = 1
 PRIM_NONE = 0xFFFFFFFF
 PRIM_SPHERE = 0x80000000
@@ -59,7 +60,7 @@ class PtError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "interior", "tri_tests", "tri_accept", "sphere_tests",
                                           "sky_lookups", "bounces", "sphere_accept", "frames", "bvh_depth", "walks",
-                                          "sky_loop_beside")]
+                                          "sky_loop_beside", "guarded", "rewalks", "guard_nodes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -108,6 +109,7 @@ ABI = [
     ("pt_accum_device_ptr", _VP, [_VP]),
     ("pt_bind_accum", _I, [_VP, _VP]),
     ("pt_trace_rays", _I, [_VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP]),
+    ("pt_trace_rays_walked", _I, [_VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("pt_group_create", _I, [C.POINTER(_I), _I, _U32, _U32, _U32, C.POINTER(_VP)]),
     ("pt_group_destroy", None, [_VP]),
     ("pt_group_last_error", C.c_char_p, [_VP]),
@@ -127,6 +129,7 @@ ABI = [
     ("pt_group_stats", _I, [_VP, C.POINTER(Stats)]),
     ("pt_bvh_build", C.c_int64, [_VP, _U32, _VP, _VP]),
     ("pt_bvh_build_sah", C.c_int64, [_VP, _U32, _VP, _VP]),
+    ("pt_bvh_build_sah_padded", C.c_int64, [_VP, _U32, _VP, _VP, _VP]),
     ("pt_plane_triangles", _I, [_VP, _VP, _VP, _VP, _U32, _VP]),
     ("pt_pack_spheres", _I, [_VP, _U32, _VP]),
     ("pt_obj_load", _I, [C.c_char_p, _VP, _U32, C.POINTER(_U32)]),
@@ -260,16 +263,22 @@ def bvh_build(triangles: np.ndarray):
     return nodes[:used].copy(), idx
 
 
-def bvh_build_sah(triangles: np.ndarray):
+def bvh_build_sah(triangles: np.ndarray, pad=None):
     """pt_bvh_build_sah: a binned-SAH tree in the reference's node format -> (nodes, triangle_indices).  Not the
-    reference's tree: what PT_FLAG_REBUILD_BVH walks (opt-in, outside the bit-for-bit contract)."""
+    reference's tree: what PT_FLAG_REBUILD_BVH walks (opt-in, outside the bit-for-bit contract).  With `pad` (one float
+    per triangle) pt_bvh_build_sah_padded: the tree over bounds grown by that much."""
     triangles = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
     n = len(triangles)
     if n == 0:
         return np.zeros(0, NODE_DTYPE), np.zeros(0, np.uint32)
     nodes = np.zeros(2 * n - 1, NODE_DTYPE)
     idx = np.zeros(n, np.uint32)
-    used = lib().pt_bvh_build_sah(_ptr(triangles), n, _ptr(nodes), _ptr(idx))
+    if pad is None:
+        used = lib().pt_bvh_build_sah(_ptr(triangles), n, _ptr(nodes), _ptr(idx))
+    else:
+        pad = np.ascontiguousarray(pad, np.float32)
+        assert pad.shape == (n,)
+        used = lib().pt_bvh_build_sah_padded(_ptr(triangles), n, _ptr(pad), _ptr(nodes), _ptr(idx))
     if used < 0:
         raise PtError(int(used), "pt_bvh_build_sah failed")
     return nodes[:used].copy(), idx
@@ -468,6 +477,17 @@ class Renderer:
         self._ck(self._l.pt_trace_rays(self._ctx, _ptr(origins), _ptr(dirs), n, _ptr(prim), _ptr(t), _ptr(p),
                                        _ptr(nrm), _ptr(front)))
         return prim, t, p, nrm, front
+
+    def trace_rays_walked(self, origins: np.ndarray, dirs: np.ndarray):
+        """pt_trace_rays_walked: trace_rays' outputs plus, per ray, which tree answered (0 / 1 / 2, see include/ptrt.h)."""
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(origins)
+        prim, t, walked = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        p, nrm, front = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.uint32)
+        self._ck(self._l.pt_trace_rays_walked(self._ctx, _ptr(origins), _ptr(dirs), n, _ptr(prim), _ptr(t), _ptr(p),
+                                              _ptr(nrm), _ptr(front), _ptr(walked)))
+        return prim, t, p, nrm, front, walked
 
 
 class RendererGroup:

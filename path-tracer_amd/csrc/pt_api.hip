@@ -54,6 +54,12 @@ struct pt_ctx {
     float4 *tri_nrm = nullptr;
     uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0, tri_base = 0;
     float4 root_pair[4] = {};
+    uint32_t walk_depth = 0;  // deepest leaf of any tree in the walk table (the traversal stacks' bound)
+    // the guard tree (PtDeviceScene::guard_on ...), if pt_set_mesh built one
+    bool guard_on = false;
+    float guard_center[3] = {}, guard_radius = 0.0f, guard_reach = 0.0f, guard_margin = 0.0f;
+    uint32_t guard_root = 0, guard_nodes = 0, guard_depth = 0;
+    float guard_pad_median = 0.0f;
 
     float4 *sky = nullptr;
     uint32_t sky_size = 0;
@@ -269,6 +275,9 @@ void free_mesh(pt_ctx *ctx)
     ctx->mesh_has_gizmo = false;
     ctx->root_token = 0;
     ctx->bvh_depth = 0;
+    ctx->walk_depth = 0;
+    ctx->guard_on = false;
+    ctx->guard_nodes = ctx->guard_depth = 0;
 }
 
 PtDeviceScene device_scene(const pt_ctx *ctx)
@@ -288,6 +297,12 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.tri_materials = (ctx->flags & PT_FLAG_TRIANGLE_MATERIALS) ? 1u : 0u;
     sc.t_min = ctx->settings.t_min;
     sc.t_max = ctx->settings.t_max;
+    sc.guard_on = ctx->guard_on ? 1u : 0u;
+    for (int k = 0; k < 3; k++) sc.guard_center[k] = ctx->guard_center[k];
+    sc.guard_radius = ctx->guard_radius;
+    sc.guard_reach = ctx->guard_reach;
+    sc.guard_margin = ctx->guard_margin;
+    sc.guard_root = ctx->guard_root;
     return sc;
 }
 
@@ -516,10 +531,123 @@ static int pt_set_flags_impl(pt_ctx *ctx, uint32_t flags)
 {
     PT_ENTER(ctx);
     ctx->scene_generation++;  // a plan made before this call is not run again
-    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS | PT_FLAG_REGROUP_SHORT | PT_FLAG_REBUILD_BVH)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
+    if (flags & ~(PT_FLAG_REFERENCE_DISPATCH | PT_FLAG_AOV | PT_FLAG_DETAILED_STATS | PT_FLAG_TILE_KERNEL | PT_FLAG_POOL_KERNEL | PT_FLAG_TRIANGLE_MATERIALS | PT_FLAG_REGROUP_SHORT | PT_FLAG_REBUILD_BVH | PT_FLAG_REFERENCE_WALK)) return fail(ctx, PT_ERR_INVALID, "pt_set_flags: unknown flag bits 0x%x", flags);
     ctx->flags = flags;
     return PT_OK;
 }
+
+// ---- the guard tree ---------------------------------------------------------------------------------------------
+// The pooled kernel's default walk (PtDeviceScene::guard_on).  The reference tree splits at spatial midpoints and a walk
+// of it takes about half as many steps again as a walk of a surface-area tree; but which hit a walk returns depends on
+// its tree where the shader's float arithmetic is ambiguous, so a different tree alone is outside the bit-for-bit
+// contract (PT_FLAG_REBUILD_BVH).  The guard tree is built so that a walk of it cannot lose a hit, and every hit it
+// returns is checked to be the reference walk's:
+//   * The triangle test (compute.wgsl:352-392) accepts a hit at float (t, u, v) when the exact ray point o + t d lies
+//     within e of the triangle, e <= 23 u |d| |e1| |e2| (|o - a| + |edge|) / |det| to first order in u = 2^-24 (two
+//     roundings per cross-product component, three per dot product, one for the reciprocal and one for each final
+//     product), and |det| >= 1e-5 for an accepted hit.  Every triangle's bounds are padded by 48 u 1e5 |e1| |e2| reach
+//     -- twice that bound for any ray with (|o - centre| + radius) max(1, |d|) <= reach -- plus an absolute term for the
+//     slab test's own roundings, and the tree is built over the padded bounds.  The point o + t d of an accepted hit is
+//     then inside every box above its triangle by more than the slab test can be wrong, so no such box is skipped or
+//     pruned while the hit could still matter: the guard walk's closest hit is the closest of ALL accepted hits.
+//   * That hit is the reference walk's too if the reference walk tests the triangle -- guaranteed when the hit point is
+//     `margin` inside the triangle's own bounds, which every reference box above it contains (checked here for the
+//     caller's tree) -- and if no other triangle is accepted at exactly the same t (flagged by the walk).
+//   * Rays out of reach, rays with a zero or non-finite direction component, and hits that fail the check walk the
+//     reference tree.
+struct GuardPlan {
+    bool on = false;
+    float center[3] = {}, radius = 0.0f, reach = 0.0f, margin = 0.0f, pad_median = 0.0f;
+    std::vector<float> pad;
+};
+static float float_above(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafter(f, 3.40282347e+38f);
+    return f;
+}
+static void plan_guard(const PtTriangle *tris, uint32_t n_tris, const PtNode *nodes, uint32_t n_nodes, const uint32_t *tri_idx,
+                       const std::vector<int32_t> &depth, GuardPlan &gp)
+{
+    gp.on = false;
+    // the mesh: finite, its bounds, its longest edge
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, edge_max = 0.0, abs_max = 0.0;
+    for (uint32_t t = 0; t < n_tris; t++) {
+        const float *v[3] = {tris[t].a, tris[t].b, tris[t].c};
+        for (int k = 0; k < 3; k++)
+            for (int a = 0; a < 3; a++) {
+                const double x = v[k][a];
+                if (!std::isfinite(x)) return;
+                mn[a] = std::min(mn[a], x);
+                mx[a] = std::max(mx[a], x);
+                abs_max = std::max(abs_max, std::fabs(x));
+            }
+    }
+    if (!(abs_max < 1e15)) return;
+    for (int a = 0; a < 3; a++) gp.center[a] = (float)(0.5 * (mn[a] + mx[a]));
+    double radius = 0.0;
+    std::vector<double> area2(n_tris), extent(n_tris);
+    for (uint32_t t = 0; t < n_tris; t++) {
+        const float *v[3] = {tris[t].a, tris[t].b, tris[t].c};
+        double e[3] = {0.0, 0.0, 0.0}, ext = 0.0;
+        for (int a = 0; a < 3; a++) {
+            const double ab = (double)v[1][a] - v[0][a], ac = (double)v[2][a] - v[0][a], bc = (double)v[2][a] - v[1][a];
+            e[0] += ab * ab; e[1] += ac * ac; e[2] += bc * bc;
+            ext = std::max(ext, std::max(std::max(v[0][a], v[1][a]), v[2][a]) - (double)std::min(std::min(v[0][a], v[1][a]), v[2][a]));
+        }
+        for (int k = 0; k < 3; k++) {
+            double r2 = 0.0;
+            for (int a = 0; a < 3; a++) r2 += ((double)v[k][a] - gp.center[a]) * ((double)v[k][a] - gp.center[a]);
+            radius = std::max(radius, std::sqrt(r2));
+        }
+        edge_max = std::max(edge_max, std::sqrt(std::max(e[0], std::max(e[1], e[2]))));
+        area2[t] = std::sqrt(e[0]) * std::sqrt(e[1]);  // |e1| |e2|
+        extent[t] = ext;
+    }
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double rb = (radius + edge_max) * 1.000001;
+    const double reach = 8.0 * rb;
+    if (!(rb > 0.0) || !(reach < 1e15)) return;
+    const double o_max = std::max(std::max(std::fabs(gp.center[0]), std::fabs(gp.center[1])), std::fabs(gp.center[2])) + reach;  // no origin in reach has a larger coordinate
+    const double slab = 8.0 * u * (abs_max + reach + o_max) + 6.0 * u * reach + 1e-30;
+    gp.pad.resize(n_tris);
+    for (uint32_t t = 0; t < n_tris; t++) gp.pad[t] = float_above(48.0 * u * 1e5 * reach * area2[t] * 1.000001 + slab);
+    gp.radius = float_above(rb);
+    gp.reach = (float)reach;
+    if ((double)gp.reach > reach) gp.reach = std::nextafter(gp.reach, 0.0f);
+    gp.margin = float_above(16.0 * u * (abs_max + o_max));
+    // worth it?  a padding that is no small part of a triangle's size makes for a tree no better than the reference's
+    {
+        std::vector<float> p2(gp.pad);
+        std::nth_element(p2.begin(), p2.begin() + n_tris / 2, p2.end());
+        std::nth_element(extent.begin(), extent.begin() + n_tris / 2, extent.end());
+        gp.pad_median = p2[n_tris / 2];
+        if (!((double)gp.pad_median * 8.0 <= extent[n_tris / 2])) return;
+    }
+    // the caller's tree: every reachable box contains what is below it (children stored after their parent)
+    for (uint32_t i = n_nodes; i-- > 0;) {
+        if (depth[i] < 0) continue;
+        const PtNode &n = nodes[i];
+        for (int a = 0; a < 3; a++)
+            if (!std::isfinite(n.min_corner[a]) || !std::isfinite(n.max_corner[a])) return;
+        if (n.triangle_count == 0) {
+            for (uint32_t c = n.left_child_index; c <= n.left_child_index + 1u; c++)
+                for (int a = 0; a < 3; a++)
+                    if (!(nodes[c].min_corner[a] >= n.min_corner[a]) || !(nodes[c].max_corner[a] <= n.max_corner[a])) return;
+        } else {
+            for (uint32_t k = 0; k < n.triangle_count; k++) {
+                const PtTriangle &tr = tris[tri_idx[n.left_child_index + k]];
+                const float *v[3] = {tr.a, tr.b, tr.c};
+                for (int q = 0; q < 3; q++)
+                    for (int a = 0; a < 3; a++)
+                        if (!(v[q][a] >= n.min_corner[a]) || !(v[q][a] <= n.max_corner[a])) return;
+            }
+        }
+    }
+    gp.on = true;
+}
+
+extern "C" int64_t pt_bvh_build_sah_padded(const void *tris, uint32_t n_tris, const float *pad, void *nodes_out, uint32_t *idx_out);
 
 static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, const void *nodes_v, uint32_t n_nodes, const uint32_t *tri_idx, uint32_t n_idx)
 {
@@ -549,7 +677,7 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     // Walk table: node pairs (32 bytes per node, stored one node late) and, from the next 64-byte boundary on, one
     // 64-byte record per triangle slot; positions are 32-byte units counted from the array's second unit.
     const uint64_t tri_first_unit = ((uint64_t)n_nodes + 2) & ~1ull;  // even: 64-byte aligned
-    const uint64_t table_units = tri_first_unit + 2 * (uint64_t)n_idx;
+    uint64_t table_units = tri_first_unit + 2 * (uint64_t)n_idx;
     if (table_units > (1ull << 27)) return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: %u nodes and %u triangle slots need a walk table of more than 4 GiB", n_nodes, n_idx);
     const uint32_t tri_base = (uint32_t)tri_first_unit - 1u;
 
@@ -589,6 +717,44 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     if (max_depth > PT_MAX_BVH_DEPTH)
         return fail(ctx, PT_ERR_LIMIT, "pt_set_mesh: BVH depth %u exceeds %u (the reference shader's own stack holds 15 entries)", max_depth, PT_MAX_BVH_DEPTH);
 
+    // The guard tree (see plan_guard), for meshes the pooled kernel takes: its triangle records behind the reference
+    // tree's (slots n_idx ..), its pairs behind those -- guard node j at unit guard_first_unit + j + 1, so that pairs
+    // (odd, even) are aligned like the reference tree's.
+    GuardPlan gp;
+    std::vector<PtNode> g_nodes;
+    std::vector<uint32_t> g_idx;
+    uint32_t n_gnodes = 0, g_depth = 0;
+    uint64_t guard_first_unit = 0;
+    if (!(ctx->flags & (PT_FLAG_REBUILD_BVH | PT_FLAG_REFERENCE_WALK)) && n_tris >= PT_POOL_MIN_TRIANGLES && nodes[0].triangle_count == 0) {
+        plan_guard(tris, n_tris, nodes, n_nodes, tri_idx, depth, gp);
+        guard_first_unit = table_units;  // (even)
+        if (gp.on && guard_first_unit + 2 * (uint64_t)n_tris + 2 * (uint64_t)n_tris + 2 > (1ull << 27)) gp.on = false;  // no room under 4 GiB: the reference tree alone
+        if (gp.on) {
+            g_nodes.resize(2 * (size_t)n_tris - 1);
+            g_idx.resize(n_tris);
+            const int64_t used = pt_bvh_build_sah_padded(tris_v, n_tris, gp.pad.data(), g_nodes.data(), g_idx.data());
+            if (used == PT_ERR_NOMEM) return fail(ctx, PT_ERR_NOMEM, "pt_set_mesh: out of host memory");
+            gp.on = used >= 3 && g_nodes[0].triangle_count == 0;
+            n_gnodes = gp.on ? (uint32_t)used : 0u;
+            // parents before children, leaves small enough for inline tokens: the builder's own guarantees, checked
+            std::vector<uint32_t> gd(n_gnodes, 0u);
+            for (uint32_t i = 0; i < n_gnodes && gp.on; i++) {
+                const PtNode &n = g_nodes[i];
+                g_depth = std::max(g_depth, gd[i]);
+                if (n.triangle_count == 0) {
+                    if (n.left_child_index <= i || (uint64_t)n.left_child_index + 1 >= n_gnodes) gp.on = false;
+                    else gd[n.left_child_index] = gd[n.left_child_index + 1] = gd[i] + 1u;
+                } else if (n.triangle_count > 7u || (uint64_t)n.left_child_index + n.triangle_count > n_tris) {
+                    gp.on = false;
+                }
+            }
+            if (g_depth > PT_MAX_BVH_DEPTH) gp.on = false;
+        }
+        if (gp.on) table_units = guard_first_unit + 2 * (uint64_t)n_tris + (((uint64_t)n_gnodes + 2) & ~1ull);
+    }
+    const uint64_t guard_node_unit = guard_first_unit + 2 * (uint64_t)n_tris;  // (even) guard node j lives at unit guard_node_unit + j + 1
+    const uint32_t n_slots = n_idx + (gp.on ? n_tris : 0u);
+
     // Sibling pairs (l, l+1), interleaved component by component so that the two slab tests of a node
     // visit are packed two-wide: {lmin.x rmin.x lmin.y rmin.y} {lmin.z rmin.z lmax.x rmax.x}
     // {lmax.y rmax.y lmax.z rmax.z} {l token, r token, 0, 0}, at the place of nodes l and l+1.
@@ -609,11 +775,12 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     // random read of it is one 64-byte half line (48-byte records cost two of them three times in four)
     bool mesh_gizmo = false;
     float4 *const h_pos = h_nodes.data() + 2 * (size_t)tri_first_unit;
-    std::vector<float4> h_nrm(3 * (size_t)n_idx);
-    for (uint32_t k = 0; k < n_idx; k++) {
-        const PtTriangle &t = tris[tri_idx[k]];
+    std::vector<float4> h_nrm(3 * (size_t)n_slots);
+    for (uint32_t k = 0; k < n_slots; k++) {
+        const uint32_t ti = k < n_idx ? tri_idx[k] : g_idx[k - n_idx];  // (the guard tree's slots follow in its own leaf order)
+        const PtTriangle &t = tris[ti];
         // edges as the shader computes them (compute.wgsl:353-354)
-        h_pos[4 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(tri_idx[k]));
+        h_pos[4 * (size_t)k] = make_float4(t.a[0], t.a[1], t.a[2], u2f(ti));
         h_pos[4 * (size_t)k + 1] = make_float4(t.b[0] - t.a[0], t.b[1] - t.a[1], t.b[2] - t.a[2], (float)t.material);
         h_pos[4 * (size_t)k + 2] = make_float4(t.c[0] - t.a[0], t.c[1] - t.a[1], t.c[2] - t.a[2], 0.0f);
         // albedo and material ride in the spare components; read only with PT_FLAG_TRIANGLE_MATERIALS
@@ -621,6 +788,23 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
         h_nrm[3 * (size_t)k + 1] = make_float4(t.nb[0], t.nb[1], t.nb[2], t.albedo[1]);
         h_nrm[3 * (size_t)k + 2] = make_float4(t.nc[0], t.nc[1], t.nc[2], t.albedo[2]);
         mesh_gizmo |= (t.material == 3u);
+    }
+    if (gp.on) {
+        auto guard_token = [&](uint32_t i) -> uint32_t {
+            const PtNode &n = g_nodes[i];
+            if (n.triangle_count == 0) return (uint32_t)guard_node_unit + n.left_child_index;  // position of its children's pair (unit - 1)
+            return PT_TOKEN_LEAF | (n.triangle_count << 28) | (tri_base + 2u * (n_idx + n.left_child_index));
+        };
+        for (uint32_t i = 0; i < n_gnodes; i++) {
+            const PtNode &n = g_nodes[i];
+            if (n.triangle_count != 0) continue;
+            const PtNode &a = g_nodes[n.left_child_index], &b = g_nodes[n.left_child_index + 1];
+            float4 *rec = &h_nodes[2 * (guard_node_unit + (size_t)n.left_child_index + 1)];
+            rec[0] = make_float4(a.min_corner[0], b.min_corner[0], a.min_corner[1], b.min_corner[1]);
+            rec[1] = make_float4(a.min_corner[2], b.min_corner[2], a.max_corner[0], b.max_corner[0]);
+            rec[2] = make_float4(a.max_corner[1], b.max_corner[1], a.max_corner[2], b.max_corner[2]);
+            rec[3] = make_float4(u2f(guard_token(n.left_child_index)), u2f(guard_token(n.left_child_index + 1)), 0.0f, 0.0f);
+        }
     }
 
     free_mesh(ctx);
@@ -641,6 +825,18 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     if (nodes[0].triangle_count == 0)
         for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
     ctx->bvh_depth = max_depth;
+    ctx->walk_depth = std::max(max_depth, gp.on ? g_depth : 0u);
+    ctx->guard_on = gp.on;
+    if (gp.on) {
+        for (int k = 0; k < 3; k++) ctx->guard_center[k] = gp.center[k];
+        ctx->guard_radius = gp.radius;
+        ctx->guard_reach = gp.reach;
+        ctx->guard_margin = gp.margin;
+        ctx->guard_root = (uint32_t)guard_node_unit + g_nodes[0].left_child_index;
+        ctx->guard_nodes = n_gnodes;
+        ctx->guard_depth = g_depth;
+        ctx->guard_pad_median = gp.pad_median;
+    }
     return PT_OK;
 }
 
@@ -834,12 +1030,12 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
     }
     use_pool = use_pool && pool_possible;
     // spill space for traversal stacks deeper than the kernels keep in LDS
-    const size_t pgs = use_pool ? pt_pool_gstack_bytes(ctx->n_cus, ctx->bvh_depth) : 0;
+    const size_t pgs = use_pool ? pt_pool_gstack_bytes(ctx->n_cus, ctx->walk_depth) : 0;
     uint32_t *pool_gstack = ctx->pool_gstack;
     if (use_static) {
         pool_gstack = pgs ? static_cast<uint32_t *>(carve(pgs)) : nullptr;
         if (pgs && !pool_gstack)
-            return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space, beyond the %llu-byte static scratch", ctx->bvh_depth, pgs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+            return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space, beyond the %llu-byte static scratch", ctx->walk_depth, pgs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
     } else if (pgs > ctx->pool_gstack_bytes) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         dev_free(ctx->pool_gstack);
@@ -941,7 +1137,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
             ctx->window_shown = std::min(ctx->window_size, ctx->ready_samples);
             ctx->ready_samples = std::min(ctx->ready_samples + 1u, ctx->window_size);
             p.time0 = time0 + f * stride;
-            PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
+            PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
             uint32_t *slot = ctx->window_ring + (size_t)(ctx->window_seq % ctx->window_size) * n_px;
             PT_HIP(ctx, pt_launch_window_push(ctx->window_frame, ctx->accum, slot, n_px, ctx->stream));
             ctx->window_seq++;
@@ -1040,7 +1236,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
         }
         p.gstack_cap = gs ? ctx->bvh_depth : 0;
         p.gstack_blocks = gs ? blocks : 0;
-        PT_HIP(ctx, pt_launch_trace(p, ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
+        PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
         done += batch;
         ctx->frames += batch;
         ctx->paths += (uint64_t)p.cols * p.rows * batch * ctx->settings.samples_per_pixel;
@@ -1233,6 +1429,9 @@ static int pt_stats_impl(pt_ctx *ctx, pt_stats_t *out)
     out->bvh_depth = ctx->bvh_depth;
     out->walks = c[9];
     out->sky_loop_beside = (ctx->main_stream && ctx->side_stream) ? 1u : 0u;
+    out->guarded = c[10];
+    out->rewalks = c[11];
+    out->guard_nodes = ctx->guard_on ? ctx->guard_nodes : 0u;
     return check_gave_up(ctx);
 }
 
@@ -1248,15 +1447,16 @@ static int pt_bind_accum_impl(pt_ctx *ctx, void *device_ptr)
     return PT_OK;
 }
 
-static int pt_trace_rays_impl(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
+static int pt_trace_rays_impl(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front,
+                             uint32_t *walked)
 {
     PT_ENTER(ctx);
     if (n == 0) return PT_OK;
     if (!origins || !dirs) return fail(ctx, PT_ERR_INVALID, "pt_trace_rays: null rays");
     if (n > (1u << 28)) return fail(ctx, PT_ERR_LIMIT, "pt_trace_rays: more than 2^28 rays");
-    // one allocation: origins | dirs | prim | t | p | normal | front
+    // one allocation: origins | dirs | prim | t | p | normal | front | walked
     const size_t fl = (size_t)n * sizeof(float);
-    const size_t total = 3 * fl * 2 + fl + fl + 3 * fl * 2 + fl;
+    const size_t total = 3 * fl * 2 + fl + fl + 3 * fl * 2 + fl + fl;
     char *buf = nullptr;
     PT_HIP(ctx, hipMalloc((void **)&buf, total));
     PtRayQuery q{};
@@ -1268,23 +1468,26 @@ static int pt_trace_rays_impl(pt_ctx *ctx, const float *origins, const float *di
     q.t = reinterpret_cast<float *>(cur); cur += fl;
     q.p = reinterpret_cast<float *>(cur); cur += 3 * fl;
     q.normal = reinterpret_cast<float *>(cur); cur += 3 * fl;
-    q.front = reinterpret_cast<uint32_t *>(cur);
+    q.front = reinterpret_cast<uint32_t *>(cur); cur += fl;
+    q.walked = reinterpret_cast<uint32_t *>(cur);
     q.n = n;
     uint32_t *gs_mem = nullptr;
-    const size_t gs = pt_ray_query_gstack_bytes(n, ctx->bvh_depth);
+    const uint32_t depth = ctx->walk_depth;  // (the deeper of the two trees a ray may walk)
+    const size_t gs = pt_ray_query_gstack_bytes(n, depth);
     hipError_t e = hipSuccess;
     if (gs) e = hipMalloc((void **)&gs_mem, gs);
     q.gstack = gs_mem;
-    q.gstack_cap = gs ? ctx->bvh_depth : 0;
+    q.gstack_cap = gs ? depth : 0;
     if (e == hipSuccess) e = hipMemcpyAsync((void *)q.origins, origins, 3 * fl, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync((void *)q.dirs, dirs, 3 * fl, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = pt_launch_ray_query(q, ctx->bvh_depth, ctx->stream);
+    if (e == hipSuccess) e = pt_launch_ray_query(q, depth, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && prim) e = hipMemcpy(prim, q.prim, fl, hipMemcpyDeviceToHost);
     if (e == hipSuccess && t) e = hipMemcpy(t, q.t, fl, hipMemcpyDeviceToHost);
     if (e == hipSuccess && p) e = hipMemcpy(p, q.p, 3 * fl, hipMemcpyDeviceToHost);
     if (e == hipSuccess && normal) e = hipMemcpy(normal, q.normal, 3 * fl, hipMemcpyDeviceToHost);
     if (e == hipSuccess && front) e = hipMemcpy(front, q.front, fl, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && walked) e = hipMemcpy(walked, q.walked, fl, hipMemcpyDeviceToHost);
     (void)hipFree(buf);
     if (gs_mem) (void)hipFree(gs_mem);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "pt_trace_rays: %s", hipGetErrorString(e));
@@ -1506,7 +1709,18 @@ int pt_bind_accum(pt_ctx *ctx, void *device_ptr)
 int pt_trace_rays(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front)
 {
     try {
-        return pt_trace_rays_impl(ctx, origins, dirs, n, prim, t, p, normal, front);
+        return pt_trace_rays_impl(ctx, origins, dirs, n, prim, t, p, normal, front, nullptr);
+    } catch (const std::bad_alloc &) {
+        return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
+    } catch (...) {
+        return fail_static(ctx, PT_ERR_INTERNAL, "internal error");
+    }
+}
+int pt_trace_rays_walked(pt_ctx *ctx, const float *origins, const float *dirs, uint32_t n, uint32_t *prim, float *t, float *p, float *normal, uint32_t *front,
+                         uint32_t *walked)
+{
+    try {
+        return pt_trace_rays_impl(ctx, origins, dirs, n, prim, t, p, normal, front, walked);
     } catch (const std::bad_alloc &) {
         return fail_static(ctx, PT_ERR_NOMEM, "out of memory");
     } catch (...) {

@@ -177,11 +177,13 @@ extern "C" {
 // (message of the last failure on this thread; pt_host_error() of pt_host.cpp reports its own helpers only)
 const char *pt_bvh_build_sah_error(void) { return g_sah_error.c_str(); }
 
-int64_t pt_bvh_build_sah(const void *tris_v, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
+// Shared body of the two entry points.  `pad` (may be null) is a per-triangle distance by which that triangle's bounds
+// are grown on every side before the tree is built over them.
+static int64_t build_sah_tree(const char *who, const void *tris_v, uint32_t n_tris, const float *pad, void *nodes_out, uint32_t *idx_out)
 {
     try {
         if (n_tris == 0) return 0;
-        if (!tris_v || !nodes_out || !idx_out) { g_sah_error = "pt_bvh_build_sah: null pointer"; return PT_ERR_INVALID; }
+        if (!tris_v || !nodes_out || !idx_out) { g_sah_error = std::string(who) + ": null pointer"; return PT_ERR_INVALID; }
         SahBuilder sb;
         sb.tris = static_cast<const PtTriangle *>(tris_v);
         sb.idx = idx_out;
@@ -196,6 +198,10 @@ int64_t pt_bvh_build_sah(const void *tris_v, uint32_t n_tris, void *nodes_out, u
                 b.mn[a] = std::min(std::min(tr.a[a], tr.b[a]), tr.c[a]);
                 b.mx[a] = std::max(std::max(tr.a[a], tr.b[a]), tr.c[a]);
                 sb.cen[3 * (size_t)t + a] = 0.5f * b.mn[a] + 0.5f * b.mx[a];
+                if (pad) {  // outwards, and one more float outwards for the rounding of the subtraction itself
+                    b.mn[a] = std::nextafter(b.mn[a] - pad[t], -3.40282347e+38f);
+                    b.mx[a] = std::nextafter(b.mx[a] + pad[t], 3.40282347e+38f);
+                }
             }
         }
         const uint32_t used = sb.build(n_tris);
@@ -214,6 +220,17 @@ int64_t pt_bvh_build_sah(const void *tris_v, uint32_t n_tris, void *nodes_out, u
         try { g_sah_error.assign("internal error"); } catch (...) {}
         return PT_ERR_INTERNAL;
     }
+}
+
+int64_t pt_bvh_build_sah(const void *tris_v, uint32_t n_tris, void *nodes_out, uint32_t *idx_out)
+{
+    return build_sah_tree("pt_bvh_build_sah", tris_v, n_tris, nullptr, nodes_out, idx_out);
+}
+
+int64_t pt_bvh_build_sah_padded(const void *tris_v, uint32_t n_tris, const float *pad, void *nodes_out, uint32_t *idx_out)
+{
+    if (n_tris != 0 && !pad) { g_sah_error = "pt_bvh_build_sah_padded: null pointer"; return PT_ERR_INVALID; }
+    return build_sah_tree("pt_bvh_build_sah_padded", tris_v, n_tris, pad, nodes_out, idx_out);
 }
 
 }  // extern "C"

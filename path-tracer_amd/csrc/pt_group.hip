@@ -360,7 +360,9 @@ int pt_group_stats(pt_group *g, pt_stats_t *out)
         out->rays += s.rays; out->paths += s.paths; out->interior += s.interior; out->tri_tests += s.tri_tests;
         out->tri_accept += s.tri_accept; out->sphere_tests += s.sphere_tests; out->sky_lookups += s.sky_lookups;
         out->bounces += s.bounces; out->sphere_accept += s.sphere_accept; out->frames += s.frames; out->walks += s.walks;
+        out->guarded += s.guarded; out->rewalks += s.rewalks;
         out->bvh_depth = s.bvh_depth;
+        out->guard_nodes = s.guard_nodes;
         out->sky_loop_beside &= s.sky_loop_beside;
     }
     return PT_OK;

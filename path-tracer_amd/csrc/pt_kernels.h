@@ -55,7 +55,7 @@
 #define PT_POOL_MISS_ITERS 32u
 #define PT_POOL_MISS_LANES 48u
 #define PT_POOL_MAX_IDLE (1u << 22)
-#define PT_NUM_COUNTERS 10  // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept, walks
+#define PT_NUM_COUNTERS 12  // rays, paths, interior, tri_tests, tri_accept, sphere_tests, sky, bounces, sphere_accept, walks, guarded, rewalks
 
 struct PtDeviceScene {
     // spheres: 3 float4 each {center, radius} {albedo, material} {1/radius, 0, 0, 0}
@@ -80,6 +80,20 @@ struct PtDeviceScene {
     uint32_t sky_size;
     uint32_t tri_materials;  // 1: triangles shade with their records' albedo and material (opt-in extension)
     float t_min, t_max;
+    // The guard tree (pooled kernel only; guard_on == 0: none).  A second tree over the same triangles, built by the
+    // library with a surface-area heuristic over triangle bounds padded by more than the triangle test's own rounding
+    // error can move a hit point (for rays within `guard_reach` of the mesh), in the same table behind the reference
+    // tree: its pairs at positions guard_root.. and its triangle records at slots n_idx.. in its own leaf order.  A ray
+    // within reach that has passed the reference root's boxes walks it instead of the reference tree -- it cannot miss a
+    // triangle that the triangle test accepts -- and its closest hit is then checked to be one the reference walk returns too (the hit point strictly inside the
+    // triangle's own bounds, no second triangle at exactly the same t); a ray that fails the check, or is out of reach,
+    // walks the reference tree.
+    uint32_t guard_on;
+    uint32_t guard_root;     // table position of the pair of the guard root's children (the guard root is always interior)
+    float guard_center[3];   // centre of the mesh's bounds
+    float guard_radius;      // no vertex is further from the centre than this (longest edge included)
+    float guard_reach;       // (|origin - centre| + radius) * max(1, |direction|) at most this: the ray may walk the guard tree
+    float guard_margin;      // a verified hit point lies this far inside the triangle's bounds on every axis
 };
 
 struct PtTraceParams {
@@ -171,6 +185,7 @@ struct PtRayQuery {
     uint32_t *prim;
     float *t, *p, *normal;
     uint32_t *front;
+    uint32_t *walked;  // may be null: per ray 0 = reference tree only, 1 = guard tree and its answer taken, 2 = guard tree, then the reference tree
     uint32_t *gstack;
     uint32_t gstack_cap;
 };

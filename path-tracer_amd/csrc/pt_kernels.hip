@@ -53,6 +53,7 @@ struct Stack {
 struct Counters {
     uint32_t rays = 0, paths = 0, interior = 0, tri_tests = 0, tri_accept = 0, sphere_tests = 0, sky = 0, bounces = 0, sphere_accept = 0;
     uint32_t walks = 0;  // rays that went on into the BVH after the sphere loop and the root visit
+    uint32_t guarded = 0, rewalks = 0;  // pooled kernel: rays that set out on the guard tree; of their hits, those sent through the reference tree again
 };
 
 // Closest-hit record kept in registers during traversal; the full record (point, normal,
@@ -138,10 +139,9 @@ __device__ __forceinline__ bool pt_camera_ray_misses_bvh(const uint32_t (&cull)[
     return out0 && out1;
 }
 
-// skip_root: the caller knows that this ray enters neither of the root's child boxes (a camera ray of a pixel outside
-// their screen rectangles): the root visit is counted but not computed.
-template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_begin_body(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root)
+// The sphere half of hitScene (compute.wgsl:218-236): every sphere in array order, closest accepted root.
+template <bool STATS>
+__device__ __forceinline__ Closest hit_spheres(const PtDeviceScene &sc, v3 o, v3 d, Counters &cn)
 {
     Closest rec;
     rec.hit = false;
@@ -149,7 +149,6 @@ __device__ __forceinline__ bool walk_begin_body(const PtDeviceScene &sc, const R
     rec.t = 0.0f;
     rec.index = 0;
     rec.u = rec.v = 0.0f;
-    const v3 o = ray.o, d = ray.d;
     // hitSphere, compute.wgsl:304-350
     const float a = dot3(d, d);
     const float inv_den = pt_rcp(2.0f * a);
@@ -184,7 +183,48 @@ __device__ __forceinline__ bool walk_begin_body(const PtDeviceScene &sc, const R
             if (STATS) cn.sphere_accept++;
         }
     }
-    w.rec = rec;
+    return rec;
+}
+
+// May this ray walk the guard tree?  Its origin within reach of the mesh, scaled by the direction's length where that
+// exceeds one (the padding of the guard tree's boxes is sized for such rays), and a finite direction with no component
+// near zero (so that every slab test is ordinary arithmetic: no infinities, no 0 * inf).  A NaN anywhere fails a
+// comparison and sends the ray to the reference tree.
+__device__ __forceinline__ bool pt_guard_in_reach(const PtDeviceScene &sc, v3 o, v3 d)
+{
+    const v3 oc = o - V3(sc.guard_center[0], sc.guard_center[1], sc.guard_center[2]);
+    // (the hardware's approximate square roots, a few ulps: the comparison below leaves a thousand times that)
+    const float dist = __builtin_amdgcn_sqrtf(dot3(oc, oc)) + sc.guard_radius;
+    const float len = pt_max(1.0f, __builtin_amdgcn_sqrtf(dot3(d, d)));
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    return dist * len * 1.0001f <= sc.guard_reach && pt_min(pt_min(ax, ay), az) >= 1e-24f && pt_max(pt_max(ax, ay), az) <= 1e24f;
+}
+
+// Is the closest hit `c` of a guard-tree walk (a triangle) one that the reference walk is certain to return as well?
+// The reference walk reaches a triangle through the boxes of its leaf and that leaf's ancestors, all of which contain
+// the triangle's own bounds.  With the hit point `margin` inside those bounds on every axis -- margin being many times
+// what the slab test's three roundings can move a box face for a ray in reach -- every one of those boxes is entered
+// before t and left after it, in float as in exact arithmetic: none of them is pruned (the prune distance never drops
+// below t, the smallest accepted t there is), the triangle is tested, and it wins with the same t, u, v.
+__device__ __forceinline__ bool pt_guard_hit_is_certain(const PtDeviceScene &sc, const Ray &ray, const Closest &c)
+{
+    const float4 *tp = pt_walk_record(sc, c.index);
+    const v3 a = f4_xyz(tp[0]), b = a + f4_xyz(tp[1]), cc = a + f4_xyz(tp[2]);
+    const v3 p = v3_fma(c.t, ray.d, ray.o);
+    const float m = sc.guard_margin;
+    const bool in_x = p.x - pt_min(pt_min(a.x, b.x), cc.x) >= m && pt_max(pt_max(a.x, b.x), cc.x) - p.x >= m;
+    const bool in_y = p.y - pt_min(pt_min(a.y, b.y), cc.y) >= m && pt_max(pt_max(a.y, b.y), cc.y) - p.y >= m;
+    const bool in_z = p.z - pt_min(pt_min(a.z, b.z), cc.z) >= m && pt_max(pt_max(a.z, b.z), cc.z) - p.z >= m;
+    return in_x && in_y && in_z && c.t < 9999.0f;
+}
+
+// skip_root: the caller knows that this ray enters neither of the root's child boxes (a camera ray of a pixel outside
+// their screen rectangles): the root visit is counted but not computed.
+template <bool STATS, typename StackT>
+__device__ __forceinline__ bool walk_begin_body(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool skip_root)
+{
+    const v3 o = ray.o, d = ray.d;
+    w.rec = hit_spheres<STATS>(sc, o, d, cn);
     w.nearest = 9999.0f;
     w.node = sc.root_token;
     w.sp = 0;
@@ -226,8 +266,9 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
 }
 
 // One node visit.  Returns true when the walk is over (stack empty, compute.wgsl:264, 292).
+// tie (may be null): set when an accepted t equals that of the triangle already held (see walk_triangle).
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
+__device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool *tie = nullptr)
 {
     const v3 o = ray.o, d = ray.d;
     const uint32_t cur = w.node;
@@ -278,6 +319,7 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
         if (v < 0.0f || u + v > 1.0f) continue;
         const float t = f * dot3(e2, q);
         if (t <= sc.t_min || t >= sc.t_max) continue;
+        if (tie && w.rec.hit && w.rec.is_tri && t == w.rec.t) *tie = true;
         if (!w.rec.hit || t < w.rec.t) {
             w.rec.hit = true;
             w.rec.is_tri = true;
@@ -411,8 +453,10 @@ __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU 
 
 // Second half, for a lane that stood at triangle `slot` with its record in q: hitTriangle, compute.wgsl:352-392 (edges
 // precomputed: same subtraction), straight-line as in walk_step_u.
+// Returns whether this triangle's accepted t equals that of the triangle already held: which of the two wins depends on
+// the order of the tests, i.e. on the tree (a guard-tree walk gives such a ray to the reference tree).
 template <bool STATS>
-__device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, float4 q0, float4 q1, float4 q2, uint32_t slot, Counters &cn)
+__device__ __forceinline__ bool walk_triangle(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, float4 q0, float4 q1, float4 q2, uint32_t slot, Counters &cn)
 {
     if (STATS) cn.tri_tests++;
     const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
@@ -424,8 +468,9 @@ __device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 
     const v3 qq = cross3(sv, e1);
     const float v = f * dot3(d, qq);
     const float t = f * dot3(e2, qq);
-    const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
-                    !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
+    const bool in_range = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t <= sc.t_min || t >= sc.t_max);
+    const bool ok = in_range && (!w.rec.hit || t < w.rec.t);
+    const bool tie = in_range && w.rec.hit && w.rec.is_tri && t == w.rec.t;
     if (ok) {
         w.rec.hit = true;
         w.rec.is_tri = true;
@@ -436,6 +481,7 @@ __device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 
         w.nearest = t;
         if (STATS) cn.tri_accept++;
     }
+    return tie;
 }
 
 // A whole step on the loaded record q (the record w.node points at), in the order that keeps the walk's chain of
@@ -448,7 +494,7 @@ __device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 
 // the read goes into `below` and is moved into w.top at the very end of the step, so no step waits for its own stack
 // read.  A push onto an empty stack and a pop of the only entry (most of them: walks are shallow) touch no memory.
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
+__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch, bool &tie)
 {
     const bool tri = w.leaf_left != 0u;
     const uint32_t slot = w.node;
@@ -504,7 +550,8 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d
     if (tri) w.leaf_left--;
     w.node = next;
     if (!over && (!tri || leave)) walk_enter(w);
-    if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
+    tie = false;
+    if (tri) tie = walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
     // (the empty asm pins the stack read's first use to this place, or the compiler folds the move back into the pop's
     // branch and waits there)
     asm volatile("" : "+v"(below));
@@ -722,6 +769,8 @@ __device__ __forceinline__ void pt_add_counters(unsigned long long *stripe_words
         if (lane == 0 && s) atomicAdd(&stripe_words[k], (unsigned long long)s);
     };
     add(0, cn.rays);
+    add(10, cn.guarded);
+    add(11, cn.rewalks);
     if (STATS) {
         add(2, cn.interior); add(3, cn.tri_tests); add(4, cn.tri_accept); add(5, cn.sphere_tests);
         add(6, cn.sky); add(7, cn.bounces); add(8, cn.sphere_accept); add(9, cn.walks);
@@ -998,9 +1047,6 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     pt_add_counters<STATS>(stripe_words, cn, lane);
 }
 
-#ifndef PT_POOL_PIPELINED_WALK
-#define PT_POOL_PIPELINED_WALK 1
-#endif
 #ifndef PT_INLINE_SPHERE_HITS
 #define PT_INLINE_SPHERE_HITS 1
 #endif
@@ -1164,6 +1210,18 @@ struct PPStack {
 // Self-checks of the pooled kernel.  None of them is expected to fire; each costs a compare on a path that is taken
 // anyway, and a violated one names itself in the launch's error word (bit per kind, read by the host after a
 // synchronisation) instead of showing up later as a hang or a stray memory access.
+// F_ID of a path slot: bit 31 the ray has hit something, bit 30 a triangle (else a sphere), bits 27..0 the sphere's index
+// or the table position of the triangle's record.  In a slot whose walk is over, bit 29: the walk was one of the guard
+// tree, bit 28: it met two triangles at the same t.  In a slot that waits for a walker, bit 28: the reference tree only.
+// A walker keeps the two flags in the top bits of its step count.
+#define PT_ID_GUARD 0x20000000u
+#define PT_ID_TIE 0x10000000u
+#define PT_ID_INDEX 0x0FFFFFFFu
+#define PT_STEPS_GUARD 0x80000000u
+#define PT_STEPS_TIE 0x40000000u
+#define PT_STEPS_COUNT 0x3FFFFFFFu
+static_assert((PT_STEPS_GUARD >> 2) == PT_ID_GUARD && (PT_STEPS_TIE >> 2) == PT_ID_TIE, "a walker's flags move into F_ID by one shift");
+
 #define PT_KERR_RING_OVERWRITE 1u  // a ring position was still occupied after the bounded wait (entry overwritten)
 #define PT_KERR_RING_EMPTY 2u      // a claimed ring position was never filled (slot id lost)
 #define PT_KERR_SLOT_ID 4u         // a ring handed out a slot id beyond the pool
@@ -1494,7 +1552,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t hid = sh.st[F_ID][p];
                 w.rec.hit = (hid >> 31) != 0;
                 w.rec.is_tri = false;
-                w.rec.index = hid & 0x3FFFFFFFu;
+                w.rec.index = hid & PT_ID_INDEX;
                 w.rec.t = __uint_as_float(sh.st[F_T][p]);
                 w.rec.u = w.rec.v = 0.0f;
                 w.inv = pt_rcp3(wray.d);
@@ -1504,12 +1562,21 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 w.leaf_left = 0;
                 walk_enter(w);
                 const uint32_t k2 = sh.st[F_V][p];
-#if PT_POOL_PIPELINED_WALK
                 if (k2 != 0xFFFFFFFFu) { w.top = k2; w.sp = 1u; }  // (the newest stack entry stays in a register)
-#else
-                if (k2 != 0xFFFFFFFFu) stack.push(w.sp++, k2);
-#endif
                 wsteps = 0;
+                if constexpr (!STATS) {
+                    // A ray within reach of the mesh leaves the reference tree here -- it has passed the reference root's
+                    // boxes -- and walks the guard tree from its root, looking only for triangles in front of its sphere hit.
+                    PT_FRESH_PARAMS(LG);
+                    if (LG.sc.guard_on != 0u && (hid & PT_ID_TIE) == 0u && pt_guard_in_reach(LG.sc, wray.o, wray.d)) {
+                        w.node = LG.sc.guard_root;
+                        w.sp = 0;
+                        w.leaf_left = 0;
+                        if (w.rec.hit) w.nearest = pt_min(9999.0f, w.rec.t);
+                        wsteps = PT_STEPS_GUARD;
+                        cn.guarded++;
+                    }
+                }
                 wbusy = true;
             }
             const unsigned long long gotm = __ballot(id != 0xFFFFFFFFu);
@@ -1532,7 +1599,6 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
             did_work = true;
             bool fin = false;
             __builtin_amdgcn_s_setprio(3);  // a walk step is short and waits on memory: let it issue ahead of shading
-#if PT_POOL_PIPELINED_WALK
             // Two steps per trip of this loop, so that the record in hand and the record in flight swap registers
             // without copies: each half consumes one and has the next one's loads under way before its triangle test.
             {
@@ -1551,24 +1617,28 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                     if (wbusy) {
                         wsteps++;
-                        if (walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
+                        bool tie;
+                        const bool over = walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last, tie);
+                        wsteps |= tie ? PT_STEPS_TIE : 0u;
+                        if (over) {
                             const uint32_t p = wpath;
                             sh.st[F_T][p] = __float_as_uint(w.rec.t);
-                            sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
+                            sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | ((wsteps & (PT_STEPS_GUARD | PT_STEPS_TIE)) >> 2) | w.rec.index;
                             sh.st[F_U][p] = __float_as_uint(w.rec.u);
                             sh.st[F_V][p] = __float_as_uint(w.rec.v);
-                            sh.st[F_COST][p] += wsteps;
+                            sh.st[F_COST][p] += wsteps & PT_STEPS_COUNT;
                             wbusy = false;
                             fin = true;
                         }
                     }
 #ifdef PT_DIAG
                     {
-                        const bool ended = fin && !wbusy && wsteps != 0u;
-                        const uint32_t b = wsteps <= 1u ? 0 : wsteps <= 2u ? 1 : wsteps <= 4u ? 2 : wsteps <= 8u ? 3 : wsteps <= 16u ? 4 : wsteps <= 32u ? 5 : wsteps <= 64u ? 6 : 7;
+                        const uint32_t ws = wsteps & PT_STEPS_COUNT;
+                        const bool ended = fin && !wbusy && ws != 0u;
+                        const uint32_t b = ws <= 1u ? 0 : ws <= 2u ? 1 : ws <= 4u ? 2 : ws <= 8u ? 3 : ws <= 16u ? 4 : ws <= 32u ? 5 : ws <= 64u ? 6 : 7;
                         for (uint32_t q = 0; q < 8u; q++) {
                             dg_len_n[q] += __popcll(__ballot(ended && b == q));
-                            dg_len_steps[q] += wave_sum((ended && b == q) ? wsteps : 0u);
+                            dg_len_steps[q] += wave_sum((ended && b == q) ? ws : 0u);
                         }
                         if (ended) wsteps = 0;  // (counted once)
                     }
@@ -1583,43 +1653,6 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     if (__ballot(wbusy) == 0ull || last) break;
                 }
             }
-#else
-            for (uint32_t k = 0;; k++) {  // (at least one step: no entry test to hoist)
-#ifdef PT_DIAG
-                dg_steps++;
-                dg_busy += __popcll(__ballot(wbusy));
-                {
-                    const uint32_t nb = (uint32_t)__popcll(__ballot(wbusy));
-                    dg_hist[nb <= 8 ? 0 : nb <= 16 ? 1 : nb <= 32 ? 2 : nb <= 48 ? 3 : 4]++;
-                }
-#endif
-                if (wbusy) {
-                    wsteps++;
-                    if (walk_step_u<STATS>(sc, wray, w, stack, cn)) {
-                        const uint32_t p = wpath;
-                        sh.st[F_T][p] = __float_as_uint(w.rec.t);
-                        sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;
-                        sh.st[F_U][p] = __float_as_uint(w.rec.u);
-                        sh.st[F_V][p] = __float_as_uint(w.rec.v);
-                        sh.st[F_COST][p] += wsteps;
-                        wbusy = false;
-                        fin = true;
-                    }
-                }
-#ifdef PT_DIAG
-                {
-                    const bool ended = fin && !wbusy && wsteps != 0u;
-                    const uint32_t b = wsteps <= 1u ? 0 : wsteps <= 2u ? 1 : wsteps <= 4u ? 2 : wsteps <= 8u ? 3 : wsteps <= 16u ? 4 : wsteps <= 32u ? 5 : wsteps <= 64u ? 6 : 7;
-                    for (uint32_t q = 0; q < 8u; q++) {
-                        dg_len_n[q] += __popcll(__ballot(ended && b == q));
-                        dg_len_steps[q] += wave_sum((ended && b == q) ? wsteps : 0u);
-                    }
-                    if (ended) wsteps = 0;  // (counted once)
-                }
-#endif
-                if (__ballot(wbusy) == 0ull || k + 1u >= PT_TUNE(P.pool_steps, PT_POOL_STEPS)) break;
-            }
-#endif
             __builtin_amdgcn_s_setprio(0);
             ring_push3(sh.ring, sh.tail, fin && !w.rec.hit, fin && w.rec.hit, false, wpath, lane, lt_mask);
             if (__ballot(fin)) {
@@ -1693,6 +1726,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 Ray cur;
                 cur.o = cur.d = V3(0.0f, 0.0f, 0.0f);
                 bool retire = false;                     // the path ends in this pass
+                bool rewalk = false;                     // the ray in hand is not shaded: it walks the reference tree first
                 v3 path_color = V3(0.0f, 0.0f, 0.0f);    // its colour (a miss: still to be multiplied by the sky texel)
                 v3 sky = V3(1.0f, 1.0f, 1.0f);
                 if (had_ray) {
@@ -1717,7 +1751,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         const uint32_t hid = sh.st[F_ID][p];
                         c.hit = true;
                         c.is_tri = ((hid >> 30) & 1u) != 0;
-                        c.index = hid & 0x3FFFFFFFu;
+                        c.index = hid & PT_ID_INDEX;
                         c.t = __uint_as_float(sh.st[F_T][p]);
                         c.u = __uint_as_float(sh.st[F_U][p]);
                         c.v = __uint_as_float(sh.st[F_V][p]);
@@ -1727,17 +1761,22 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             initial_d = V3(__uint_as_float(sh.st[FL::IDIR][p]), __uint_as_float(sh.st[FL::IDIR + 1][p]), __uint_as_float(sh.st[FL::IDIR + 2][p]));
                             limit = sh.st[FL::LIMIT][p];
                         }
-                        uint32_t prim;
-                        v3 result = V3(0.0f, 0.0f, 0.0f);
-                        const bool path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
-                        if (want_aov) {
-                            L.aov_prim[(size_t)y * L.width + x] = prim;
-                            L.aov_t[(size_t)y * L.width + x] = c.t;
-                            want_aov = false;
+                        // A triangle found on the guard tree counts only if the reference walk is certain to return the same
+                        // one; otherwise the same ray walks the reference tree (nothing of the path has changed yet).
+                        if constexpr (!STATS) rewalk = c.is_tri && (hid & PT_ID_GUARD) != 0u && ((hid & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(sc, cur, c));
+                        if (!rewalk) {
+                            uint32_t prim;
+                            v3 result = V3(0.0f, 0.0f, 0.0f);
+                            const bool path_done = shade_ray<STATS, GIZMO>(sc, cur, c, color, seed, bounce, limit, initial_d, result, prim, cn);
+                            if (want_aov) {
+                                L.aov_prim[(size_t)y * L.width + x] = prim;
+                                L.aov_t[(size_t)y * L.width + x] = c.t;
+                                want_aov = false;
+                            }
+                            // rayColor returns: the path's colour, or the throughput when the bounces run out (compute.wgsl:121)
+                            retire = path_done || bounce >= limit;
+                            path_color = path_done ? result : color;
                         }
-                        // rayColor returns: the path's colour, or the throughput when the bounces run out (compute.wgsl:121)
-                        retire = path_done || bounce >= limit;
-                        path_color = path_done ? result : color;
                     }
                 }
 #ifdef PT_DIAG
@@ -1798,14 +1837,15 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #ifdef PT_DIAG
                     if (!HITS) { const unsigned long long t = clock64(); dg_sec[2] += t - dg_s2; dg_s2 = t; }
 #endif
-                    cn.rays++;
+                    if (rewalk) cn.rewalks++;
+                    else cn.rays++;
                     // spheres + root visit; a surviving ray goes to PENDING with its first node(s)
                     Walk nw;
                     uint32_t k2 = 0xFFFFFFFFu;
                     bool need_walk;
                     {
                         PT_FRESH_PARAMS(L);
-                        need_walk = walk_begin_pool<STATS>(L.sc, cur, nw, k2, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y));
+                        need_walk = walk_begin_pool<STATS>(L.sc, cur, nw, k2, cn, !rewalk && bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y));
                     }
 #ifdef PT_DIAG
                     if (!HITS) { const unsigned long long t = clock64(); dg_sec[3] += t - dg_s2; dg_s2 = t; }
@@ -1813,7 +1853,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
                     sh.st[F_DX][p] = __float_as_uint(cur.d.x); sh.st[F_DY][p] = __float_as_uint(cur.d.y); sh.st[F_DZ][p] = __float_as_uint(cur.d.z);
                     sh.st[F_T][p] = __float_as_uint(nw.rec.t);
-                    sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
+                    sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | (rewalk ? PT_ID_TIE : 0u) | nw.rec.index;  // (in a pending slot: reference tree only)
                     sh.st[F_U][p] = need_walk ? nw.node : 0u;
                     sh.st[F_V][p] = need_walk ? k2 : 0u;
                     sh.st[F_COLR][p] = __float_as_uint(color.x); sh.st[F_COLG][p] = __float_as_uint(color.y); sh.st[F_COLB][p] = __float_as_uint(color.z);
@@ -2184,7 +2224,27 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     // (tuning builds: the ray's traversal steps ride in the upper bits of `front`, for tools/step_latency.py)
     const Closest c = hit_scene<true>(Q.sc, r, stack, cn);
 #else
-    const Closest c = hit_scene<false>(Q.sc, r, stack, cn);
+    // Where the mesh has a guard tree, the pooled kernel's scheme, ray by ray: a ray in reach walks the guard tree, a
+    // triangle found there counts if it is certain to be the reference walk's as well, and everything else walks the
+    // reference tree.  (This is also how that scheme is tested on rays aimed at edges, vertices and grazing angles.)
+    Closest c;
+    bool settled = false;
+    if (Q.sc.guard_on != 0u && pt_guard_in_reach(Q.sc, r.o, r.d)) {
+        Walk w;
+        w.rec = hit_spheres<false>(Q.sc, r.o, r.d, cn);
+        w.nearest = w.rec.hit ? pt_min(9999.0f, w.rec.t) : 9999.0f;
+        w.node = Q.sc.guard_root;
+        w.sp = 0;
+        w.inv = pt_rcp3(r.d);
+        bool tie = false;
+        while (!walk_step<false>(Q.sc, r, w, stack, cn, &tie)) {}
+        c = w.rec;
+        settled = !(c.hit && c.is_tri) || (!tie && pt_guard_hit_is_certain(Q.sc, r, c));
+        if (Q.walked) Q.walked[i] = settled ? 1u : 2u;
+    } else if (Q.walked) {
+        Q.walked[i] = 0u;
+    }
+    if (!settled) c = hit_scene<false>(Q.sc, r, stack, cn);
 #endif
     const HitRecord h = make_record(Q.sc, r, c);
     if (Q.prim) Q.prim[i] = h.prim;

@@ -24,7 +24,9 @@ def _render(pt, scene, w, h, st, sky, flags, calls):
             r.render_frames(*c)
         else:
             r.render(c)
-    out = (r.read_sum().copy(),) + tuple(a.copy() for a in r.read_aov()) + (r.stats(),)
+    # (which tree a ray walked is the pooled kernel's own business: not part of what the two kernels must agree on)
+    counters = {k: v for k, v in r.stats().items() if k not in ("guarded", "rewalks")}
+    out = (r.read_sum().copy(),) + tuple(a.copy() for a in r.read_aov()) + (counters,)
     r.close()
     return out
 
