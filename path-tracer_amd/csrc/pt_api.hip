@@ -1120,11 +1120,11 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
         p.n_frames = 1;
         p.accum = ctx->window_frame;
         p.gstack_cap = 0;
-        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->n_tiles, ctx->bvh_depth);
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->n_tiles, ctx->walk_depth);
         if (gs) {
             int rc = ensure_gstack(ctx, gs);
             if (rc != PT_OK) return rc;
-            p.gstack_cap = ctx->bvh_depth;
+            p.gstack_cap = ctx->walk_depth;
             p.gstack_blocks = ctx->n_tiles;
         }
         p.gstack = ctx->gstack;
@@ -1137,7 +1137,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
             ctx->window_shown = std::min(ctx->window_size, ctx->ready_samples);
             ctx->ready_samples = std::min(ctx->ready_samples + 1u, ctx->window_size);
             p.time0 = time0 + f * stride;
-            PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
+            PT_HIP(ctx, pt_launch_trace(p, ctx->walk_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
             uint32_t *slot = ctx->window_ring + (size_t)(ctx->window_seq % ctx->window_size) * n_px;
             PT_HIP(ctx, pt_launch_window_push(ctx->window_frame, ctx->accum, slot, n_px, ctx->stream));
             ctx->window_seq++;
@@ -1162,7 +1162,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
             // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: above the
             // limit the frames run one after the other, one item per tile, with no such rows at all
             const uint64_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
-            const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->bvh_depth));
+            const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->walk_depth));
             const uint64_t limit = use_static ? PT_STATIC_SCRATCH_BYTES - static_mark - 4096u : PT_SHORT_LAUNCH_SCRATCH_LIMIT;
             if (bytes > limit) bs.min_planned_frames = regroup_frames;  // frame after frame, one item per tile
         }
@@ -1223,20 +1223,20 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
         bs.partial = partial;
         bs.item_cap = item_cap;
         // spill space for traversal stacks deeper than the per-tile kernel keeps in LDS
-        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->bvh_depth);
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->walk_depth);
         p.gstack = ctx->gstack;
         if (gs && use_static) {
             p.gstack = static_cast<uint32_t *>(carve(gs));
             if (!p.gstack)
-                return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space for this launch, beyond what is left of the %llu-byte static scratch", ctx->bvh_depth, gs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+                return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space for this launch, beyond what is left of the %llu-byte static scratch", ctx->walk_depth, gs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
         } else if (gs) {
             int rc = ensure_gstack(ctx, gs);
             if (rc != PT_OK) return rc;
             p.gstack = ctx->gstack;
         }
-        p.gstack_cap = gs ? ctx->bvh_depth : 0;
+        p.gstack_cap = gs ? ctx->walk_depth : 0;
         p.gstack_blocks = gs ? blocks : 0;
-        PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
+        PT_HIP(ctx, pt_launch_trace(p, ctx->walk_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
         done += batch;
         ctx->frames += batch;
         ctx->paths += (uint64_t)p.cols * p.rows * batch * ctx->settings.samples_per_pixel;

@@ -358,8 +358,9 @@ __device__ __forceinline__ void walk_enter(WalkU &w)
     }
 }
 
+// tie: set (never cleared) when an accepted t equals that of the triangle already held (see walk_triangle).
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn)
+__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn, bool &tie)
 {
     const v3 o = ray.o, d = ray.d;
     const bool tri = w.leaf_left != 0u;
@@ -412,8 +413,9 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             const v3 q = cross3(s, e1);
             const float v = f * dot3(d, q);
             const float t = f * dot3(e2, q);
-            const bool ok = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) &&
-                            !(t <= sc.t_min || t >= sc.t_max) && (!w.rec.hit || t < w.rec.t);
+            const bool in_range = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t <= sc.t_min || t >= sc.t_max);
+            const bool ok = in_range && (!w.rec.hit || t < w.rec.t);
+            tie = tie || (in_range && w.rec.hit && w.rec.is_tri && t == w.rec.t);
             if (ok) {
                 w.rec.hit = true;
                 w.rec.is_tri = true;
@@ -954,6 +956,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     w.sp = 0;
     w.leaf_left = 0;
     w.top = 0;
+    // The guard tree (PtDeviceScene::guard_on), as in the pooled kernel: a ray in reach that has passed the reference root's
+    // boxes walks it; a triangle found there is shaded only if the reference walk is certain to return the same one, and
+    // otherwise the lane sets the same ray up again (redo) and walks the reference tree.
+    bool on_guard = false, tie = false, redo = false;
 
     for (;;) {
         const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
@@ -971,7 +977,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
             if (mode == M_SHADE) {
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
-                if (!need_new) {
+                if constexpr (!STATS) {
+                    if (!need_new && on_guard && w.rec.hit && w.rec.is_tri) {
+                        PT_FRESH_PARAMS(L);
+                        redo = tie || !pt_guard_hit_is_certain(L.sc, cur, w.rec);
+                    }
+                }
+                if (!need_new && !redo) {
                     PT_FRESH_PARAMS(L);
                     uint32_t prim;
                     path_done = shade_ray<STATS, GIZMO>(L.sc, cur, w.rec, color, seed, bounce, limit, initial_d, result, prim, cn);
@@ -981,15 +993,28 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                         want_aov = false;
                     }
                 }
-                {
+                if (!redo) {
                     PT_FRESH_PARAMS(L);
                     advance(L, path_done, result);
                 }
                 if (active) {
                     PT_FRESH_PARAMS(L);
-                    cn.rays++;
-                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
+                    if (redo) cn.rewalks++;
+                    else cn.rays++;
+                    mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, !redo && bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
+                    on_guard = false;
+                    tie = false;
+                    if constexpr (!STATS) {
+                        if (mode == M_WALK && !redo && L.sc.guard_on != 0u && pt_guard_in_reach(L.sc, cur.o, cur.d)) {
+                            on_guard = true;
+                            cn.guarded++;
+                            w.node = L.sc.guard_root;
+                            w.sp = 0;
+                            if (w.rec.hit) w.nearest = pt_min(9999.0f, w.rec.t);
+                        }
+                    }
+                    redo = false;
                     if (mode == M_WALK) walk_enter(w);
                 } else {
                     mode = M_DONE;
@@ -1011,7 +1036,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
             g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (mode == M_WALK) {
-            if (walk_step_u<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
+            if (walk_step_u<STATS>(sc, cur, w, stack, cn, tie)) mode = M_SHADE;
         }
 #ifdef PT_DIAG
         { const unsigned long long t = clock64(); diag_a += t - diag_s; }

@@ -1,4 +1,4 @@
-"""The pooled kernel's second tree (see PT_FLAG_REFERENCE_WALK in include/ptrt.h): rays within reach of the mesh walk a
+"""The megakernels' second tree (see PT_FLAG_REFERENCE_WALK in include/ptrt.h): rays within reach of the mesh walk a
 surface-area tree that pt_set_mesh builds over padded triangle bounds, every triangle hit found there is checked to be
 the one a walk of the caller's tree returns, and whatever fails the check walks the caller's tree.  The bar is the one of
 every other parity test: the same bits as a walk of the caller's tree alone, and as the oracle.  These cases aim at the
@@ -20,17 +20,21 @@ def _render(pt, scene, w, h, st, sky, flags, frames, time0=11):
 
 
 def _both_walks(pt, scene, w, h, st, sky, frames=12):
-    """Pooled kernel with the second tree, pooled kernel on the caller's tree only, per-tile kernel: bit for bit (a launch
-    of fewer than 16 frames adds every frame on its own, in order, whichever kernel runs it)."""
+    """Both kernels with the second tree, both on the caller's tree only: bit for bit (a launch of fewer than 16 frames
+    adds every frame on its own, in order, whichever kernel runs it).  Returns the pooled kernel's counters."""
     assert frames < 16
-    g = _render(pt, scene, w, h, st, sky, pt.PT_FLAG_POOL_KERNEL, frames)
-    r = _render(pt, scene, w, h, st, sky, pt.PT_FLAG_POOL_KERNEL | pt.PT_FLAG_REFERENCE_WALK, frames)
-    t = _render(pt, scene, w, h, st, sky, pt.PT_FLAG_TILE_KERNEL, frames)
-    assert r[2]["guard_nodes"] == 0 and r[2]["guarded"] == 0 and r[2]["rewalks"] == 0
-    assert t[2]["guarded"] == 0, "the per-tile kernel walks the caller's tree only"
-    for other, name in ((r, "the caller's tree alone"), (t, "the per-tile kernel")):
+    runs = {}
+    for kernel, kflag in (("pooled", pt.PT_FLAG_POOL_KERNEL), ("per-tile", pt.PT_FLAG_TILE_KERNEL)):
+        for walk, wflag in (("both trees", 0), ("caller's tree", pt.PT_FLAG_REFERENCE_WALK)):
+            runs[kernel, walk] = _render(pt, scene, w, h, st, sky, kflag | wflag, frames)
+    g = runs["pooled", "both trees"]
+    for (kernel, walk), other in runs.items():
+        if walk == "caller's tree":
+            assert other[2]["guard_nodes"] == 0 and other[2]["guarded"] == 0 and other[2]["rewalks"] == 0
+        else:
+            assert other[2]["guard_nodes"] == g[2]["guard_nodes"] and (other[2]["guarded"] > 0) == (g[2]["guarded"] > 0)
         diff = int((g[0].view(np.uint32) != other[0].view(np.uint32)).sum())
-        assert diff == 0, f"{diff} of {g[0].size} sums differ from {name}"
+        assert diff == 0, f"{diff} of {g[0].size} sums differ from the {kernel} kernel on {walk}"
         assert np.array_equal(g[1][0], other[1][0]) and np.array_equal(g[1][1].view(np.uint32), other[1][1].view(np.uint32))
         assert g[2]["rays"] == other[2]["rays"]
     # a long launch, split into work items of several frames: the two pooled runs plan alike (nothing measured yet)

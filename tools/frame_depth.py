@@ -1,6 +1,6 @@
 """GPU box: time of one 1-spp 1080p dispatch of the bench scene against path depth (is a single frame bound by the
 longest path's chain of dependent traversal steps?).  PTRT_KERNEL=pool|tile forces a megakernel; REBUILD=1 walks the
-library's own tree (PT_FLAG_REBUILD_BVH)."""
+library's own tree (PT_FLAG_REBUILD_BVH); REFWALK=1 walks the reference tree only (PT_FLAG_REFERENCE_WALK)."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ import _pkgload
 pt = _pkgload.load()
 scenes = importlib.import_module("path_tracer_amd.scenes")
 scene = scenes.bunny()
-flags = pt.PT_FLAG_REBUILD_BVH if os.environ.get("REBUILD") == "1" else 0
+flags = (pt.PT_FLAG_REBUILD_BVH if os.environ.get("REBUILD") == "1" else 0) | (pt.PT_FLAG_REFERENCE_WALK if os.environ.get("REFWALK") == "1" else 0)
 for sky in (int(os.environ.get("SKY", "4096")),):
     pano = scenes.sky_equirect(min(4096, sky * 2), min(2048, sky))
     for depth in (1, 2, 4, 8, 16, 32):
