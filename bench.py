@@ -321,7 +321,7 @@ def main():
         k_s = k_ms * 1e-3
         valu_tflops = flops / k_s / 1e12
         valu_frac = valu_tflops / FP32_VALU_PEAK_TFLOPS
-        traffic, traffic_src = find_traffic(args.workload, launch[2], "sah" if args.rebuild_bvh else "reference")
+        traffic, traffic_src = find_traffic(args.workload, launch[2], "sah" if args.rebuild_bvh else "reference-walk-only" if args.reference_walk else "reference")
         fabric_gbs = traffic / k_s / 1e9 if traffic else None
         fabric_frac = fabric_gbs / HBM_PEAK_GBS if traffic else None
         # Which roof: where the walk's working set lives.  Nodes + triangles + normals below the Infinity Cache's size are

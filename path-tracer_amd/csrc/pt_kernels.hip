@@ -62,9 +62,14 @@ struct Closest {
     bool hit;
     bool is_tri;
     float t;
-    uint32_t index;  // sphere index, or the walk-table position of the triangle's record
+    uint32_t index;  // sphere index, or the walk-table position of the triangle's record; after a walk, PT_ID_TIE on top of
+                     // it if a later triangle was accepted by the triangle test at exactly the held t (which of the two a walk
+                     // keeps is the order of its tests, i.e. the tree's): consumers mask with PT_ID_INDEX
     float u, v;
 };
+
+#define PT_ID_TIE 0x10000000u
+#define PT_ID_INDEX 0x0FFFFFFFu
 
 struct HitRecord {
     bool hit;
@@ -200,6 +205,14 @@ __device__ __forceinline__ bool pt_guard_in_reach(const PtDeviceScene &sc, v3 o,
     return dist * len * 1.0001f <= sc.guard_reach && pt_min(pt_min(ax, ay), az) >= 1e-24f && pt_max(pt_max(ax, ay), az) <= 1e24f;
 }
 
+// Pooled kernel: does the ray of a path slot whose flag word (F_FS) is `fs` walk the guard tree (of a scene that has
+// one)?  Asked twice with the same answer: by the walker that picks the ray up, and by the pass over hits that shades what
+// the walk found.  Bit 2 of the flag word: a ray sent back for a walk of the reference tree.
+__device__ __forceinline__ bool pt_ray_walks_guard(const PtDeviceScene &sc, v3 o, v3 d, uint32_t fs)
+{
+    return (fs & 4u) == 0u && pt_guard_in_reach(sc, o, d);
+}
+
 // Is the closest hit `c` of a guard-tree walk (a triangle) one that the reference walk is certain to return as well?
 // The reference walk reaches a triangle through the boxes of its leaf and that leaf's ancestors, all of which contain
 // the triangle's own bounds.  With the hit point `margin` inside those bounds on every axis -- margin being many times
@@ -208,7 +221,7 @@ __device__ __forceinline__ bool pt_guard_in_reach(const PtDeviceScene &sc, v3 o,
 // below t, the smallest accepted t there is), the triangle is tested, and it wins with the same t, u, v.
 __device__ __forceinline__ bool pt_guard_hit_is_certain(const PtDeviceScene &sc, const Ray &ray, const Closest &c)
 {
-    const float4 *tp = pt_walk_record(sc, c.index);
+    const float4 *tp = pt_walk_record(sc, c.index & PT_ID_INDEX);
     const v3 a = f4_xyz(tp[0]), b = a + f4_xyz(tp[1]), cc = a + f4_xyz(tp[2]);
     const v3 p = v3_fma(c.t, ray.d, ray.o);
     const float m = sc.guard_margin;
@@ -266,9 +279,8 @@ __device__ __forceinline__ bool walk_begin(const PtDeviceScene &sc, const Ray &r
 }
 
 // One node visit.  Returns true when the walk is over (stack empty, compute.wgsl:264, 292).
-// tie (may be null): set when an accepted t equals that of the triangle already held (see walk_triangle).
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn, bool *tie = nullptr)
+__device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ray, Walk &w, StackT stack, Counters &cn)
 {
     const v3 o = ray.o, d = ray.d;
     const uint32_t cur = w.node;
@@ -319,7 +331,7 @@ __device__ __forceinline__ bool walk_step(const PtDeviceScene &sc, const Ray &ra
         if (v < 0.0f || u + v > 1.0f) continue;
         const float t = f * dot3(e2, q);
         if (t <= sc.t_min || t >= sc.t_max) continue;
-        if (tie && w.rec.hit && w.rec.is_tri && t == w.rec.t) *tie = true;
+        if (t == w.nearest) w.rec.index |= PT_ID_TIE;  // (see walk_triangle)
         if (!w.rec.hit || t < w.rec.t) {
             w.rec.hit = true;
             w.rec.is_tri = true;
@@ -358,9 +370,8 @@ __device__ __forceinline__ void walk_enter(WalkU &w)
     }
 }
 
-// tie: set (never cleared) when an accepted t equals that of the triangle already held (see walk_triangle).
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn, bool &tie)
+__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn)
 {
     const v3 o = ray.o, d = ray.d;
     const bool tri = w.leaf_left != 0u;
@@ -415,7 +426,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
             const float t = f * dot3(e2, q);
             const bool in_range = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t <= sc.t_min || t >= sc.t_max);
             const bool ok = in_range && (!w.rec.hit || t < w.rec.t);
-            tie = tie || (in_range && w.rec.hit && w.rec.is_tri && t == w.rec.t);
+            if (in_range && t == w.nearest) w.rec.index |= PT_ID_TIE;  // (see walk_triangle)
             if (ok) {
                 w.rec.hit = true;
                 w.rec.is_tri = true;
@@ -455,10 +466,12 @@ __device__ __forceinline__ void walk_fetch(const PtDeviceScene &sc, const WalkU 
 
 // Second half, for a lane that stood at triangle `slot` with its record in q: hitTriangle, compute.wgsl:352-392 (edges
 // precomputed: same subtraction), straight-line as in walk_step_u.
-// Returns whether this triangle's accepted t equals that of the triangle already held: which of the two wins depends on
-// the order of the tests, i.e. on the tree (a guard-tree walk gives such a ray to the reference tree).
+// A hit that the test accepts at exactly the t already held marks the held record (PT_ID_TIE): which of the two a walk
+// ends up with is the order of its tests, i.e. the tree's, and a guard-tree walk gives such a ray to the reference tree.
+// (Compared with the prune distance: on the guard tree that is the held t whatever is held, on the reference tree the
+// held triangle's.  A closer hit accepted later replaces the record and the mark with it.)
 template <bool STATS>
-__device__ __forceinline__ bool walk_triangle(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, float4 q0, float4 q1, float4 q2, uint32_t slot, Counters &cn)
+__device__ __forceinline__ void walk_triangle(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, float4 q0, float4 q1, float4 q2, uint32_t slot, Counters &cn)
 {
     if (STATS) cn.tri_tests++;
     const v3 e1 = f4_xyz(q1), e2 = f4_xyz(q2);
@@ -472,7 +485,7 @@ __device__ __forceinline__ bool walk_triangle(const PtDeviceScene &sc, v3 o, v3 
     const float t = f * dot3(e2, qq);
     const bool in_range = !(a > -0.00001f && a < 0.00001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t <= sc.t_min || t >= sc.t_max);
     const bool ok = in_range && (!w.rec.hit || t < w.rec.t);
-    const bool tie = in_range && w.rec.hit && w.rec.is_tri && t == w.rec.t;
+    if (in_range && t == w.nearest) w.rec.index |= PT_ID_TIE;
     if (ok) {
         w.rec.hit = true;
         w.rec.is_tri = true;
@@ -483,7 +496,6 @@ __device__ __forceinline__ bool walk_triangle(const PtDeviceScene &sc, v3 o, v3 
         w.nearest = t;
         if (STATS) cn.tri_accept++;
     }
-    return tie;
 }
 
 // A whole step on the loaded record q (the record w.node points at), in the order that keeps the walk's chain of
@@ -496,7 +508,7 @@ __device__ __forceinline__ bool walk_triangle(const PtDeviceScene &sc, v3 o, v3 
 // the read goes into `below` and is moved into w.top at the very end of the step, so no step waits for its own stack
 // read.  A push onto an empty stack and a pop of the only entry (most of them: walks are shallow) touch no memory.
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch, bool &tie)
+__device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d, WalkU &w, WalkQ q, StackT stack, Counters &cn, WalkQ &qn, bool prefetch)
 {
     const bool tri = w.leaf_left != 0u;
     const uint32_t slot = w.node;
@@ -552,8 +564,7 @@ __device__ __forceinline__ bool walk_consume(const PtDeviceScene &sc, v3 o, v3 d
     if (tri) w.leaf_left--;
     w.node = next;
     if (!over && (!tri || leave)) walk_enter(w);
-    tie = false;
-    if (tri) tie = walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
+    if (tri) walk_triangle<STATS>(sc, o, d, w, q.q0, q.q1, q.q2, slot, cn);
     // (the empty asm pins the stack read's first use to this place, or the compiler folds the move back into the pop's
     // branch and waits there)
     asm volatile("" : "+v"(below));
@@ -606,9 +617,10 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
     if (!c.hit) return h;
     h.p = v3_fma(c.t, ray.d, ray.o);
     v3 on;
+    const uint32_t index = c.index & PT_ID_INDEX;  // (without the walk's PT_ID_TIE mark)
     if (c.is_tri) {
-        const float4 *tp = pt_walk_record(sc, c.index);  // c.index: table position of the triangle's record
-        const float4 *tn = sc.tri_nrm + 3 * (size_t)((c.index - sc.tri_base) >> 1);
+        const float4 *tp = pt_walk_record(sc, index);  // table position of the triangle's record
+        const float4 *tn = sc.tri_nrm + 3 * (size_t)((index - sc.tri_base) >> 1);
         const v3 an = f4_xyz(tn[0]), bn = f4_xyz(tn[1]), cnn = f4_xyz(tn[2]);
         const float w = (1.0f - c.u) - c.v;
         const v3 n = V3(pt_fma(cnn.x, c.v, pt_fma(bn.x, c.u, an.x * w)), pt_fma(cnn.y, c.v, pt_fma(bn.y, c.u, an.y * w)),
@@ -622,11 +634,11 @@ __device__ __forceinline__ HitRecord make_record(const PtDeviceScene &sc, const 
         }
         h.prim = __float_as_uint(tp[0].w);
     } else {
-        const float4 s0 = sc.spheres[3 * c.index], s1 = sc.spheres[3 * c.index + 1];
-        on = (h.p - f4_xyz(s0)) * sc.spheres[3 * c.index + 2].x;
+        const float4 s0 = sc.spheres[3 * index], s1 = sc.spheres[3 * index + 1];
+        on = (h.p - f4_xyz(s0)) * sc.spheres[3 * index + 2].x;
         h.att = f4_xyz(s1);
         h.material = s1.w;
-        h.prim = 0x80000000u | c.index;
+        h.prim = 0x80000000u | index;
     }
     h.front = dot3(ray.d, on) < 0.0f;
     h.normal = h.front ? on : -on;
@@ -959,7 +971,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
     // The guard tree (PtDeviceScene::guard_on), as in the pooled kernel: a ray in reach that has passed the reference root's
     // boxes walks it; a triangle found there is shaded only if the reference walk is certain to return the same one, and
     // otherwise the lane sets the same ray up again (redo) and walks the reference tree.
-    bool on_guard = false, tie = false, redo = false;
+    bool on_guard = false, redo = false;
 
     for (;;) {
         const unsigned long long waiting = __ballot(mode == M_SHADE), walking = __ballot(mode == M_WALK);
@@ -980,7 +992,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                 if constexpr (!STATS) {
                     if (!need_new && on_guard && w.rec.hit && w.rec.is_tri) {
                         PT_FRESH_PARAMS(L);
-                        redo = tie || !pt_guard_hit_is_certain(L.sc, cur, w.rec);
+                        redo = (w.rec.index & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(L.sc, cur, w.rec);
                     }
                 }
                 if (!need_new && !redo) {
@@ -1004,7 +1016,6 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                     mode = walk_begin<STATS>(L.sc, cur, w, stack, cn, !redo && bounce == 0u && pt_camera_ray_misses_bvh(L.cull, x, y)) ? M_WALK : M_SHADE;
                     w.leaf_left = 0;
                     on_guard = false;
-                    tie = false;
                     if constexpr (!STATS) {
                         if (mode == M_WALK && !redo && L.sc.guard_on != 0u && pt_guard_in_reach(L.sc, cur.o, cur.d)) {
                             on_guard = true;
@@ -1036,7 +1047,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
             g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (mode == M_WALK) {
-            if (walk_step_u<STATS>(sc, cur, w, stack, cn, tie)) mode = M_SHADE;
+            if (walk_step_u<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
         }
 #ifdef PT_DIAG
         { const unsigned long long t = clock64(); diag_a += t - diag_s; }
@@ -1142,7 +1153,7 @@ enum : uint32_t {
     F_U, F_V,                            // barycentrics; while PENDING: node token to visit, far child (or none)
     F_COLR, F_COLG, F_COLB, F_SEED, F_BOUNCE,
     F_FRAME,                             // frame being rendered
-    F_FS,                                // have_ray | want_aov << 1 | sample << 2
+    F_FS,                                // have_ray | want_aov << 1 | reference tree only << 2 | sample << 3
     F_XY, F_FEND, F_PIDX,                // the job: pixel x | y << 16, end frame, index of its float4 of sums
     F_COST,                              // work estimate of the job so far
     F_BASE
@@ -1235,18 +1246,8 @@ struct PPStack {
 // Self-checks of the pooled kernel.  None of them is expected to fire; each costs a compare on a path that is taken
 // anyway, and a violated one names itself in the launch's error word (bit per kind, read by the host after a
 // synchronisation) instead of showing up later as a hang or a stray memory access.
-// F_ID of a path slot: bit 31 the ray has hit something, bit 30 a triangle (else a sphere), bits 27..0 the sphere's index
-// or the table position of the triangle's record.  In a slot whose walk is over, bit 29: the walk was one of the guard
-// tree, bit 28: it met two triangles at the same t.  In a slot that waits for a walker, bit 28: the reference tree only.
-// A walker keeps the two flags in the top bits of its step count.
-#define PT_ID_GUARD 0x20000000u
-#define PT_ID_TIE 0x10000000u
-#define PT_ID_INDEX 0x0FFFFFFFu
-#define PT_STEPS_GUARD 0x80000000u
-#define PT_STEPS_TIE 0x40000000u
-#define PT_STEPS_COUNT 0x3FFFFFFFu
-static_assert((PT_STEPS_GUARD >> 2) == PT_ID_GUARD && (PT_STEPS_TIE >> 2) == PT_ID_TIE, "a walker's flags move into F_ID by one shift");
-
+// F_ID of a path slot: bit 31 the ray has hit something, bit 30 a triangle (else a sphere), bit 28 PT_ID_TIE, bits 27..0
+// the sphere's index or the table position of the triangle's record.
 #define PT_KERR_RING_OVERWRITE 1u  // a ring position was still occupied after the bounded wait (entry overwritten)
 #define PT_KERR_RING_EMPTY 2u      // a claimed ring position was never filled (slot id lost)
 #define PT_KERR_SLOT_ID 4u         // a ring handed out a slot id beyond the pool
@@ -1535,6 +1536,11 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
     uint32_t idle = 0;
     while (idle < PT_TUNE(P.max_idle, PT_POOL_MAX_IDLE)) {
         bool did_work = false;
+        // (the wave's index, derived anew every trip behind an opaque copy of the thread id: two instructions, instead of a
+        // scalar register held -- or spilled -- for the whole loop)
+        uint32_t tid_now = tid;
+        asm volatile("" : "+v"(tid_now));
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(tid_now >> 6);
         const bool relaxed = idle >= 2u;      // nothing to do twice in a row: shade whatever is ready
         const bool desperate = idle >= 32u;   // still nothing: walk whatever is pending
 #ifdef PT_DIAG
@@ -1592,13 +1598,13 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 if constexpr (!STATS) {
                     // A ray within reach of the mesh leaves the reference tree here -- it has passed the reference root's
                     // boxes -- and walks the guard tree from its root, looking only for triangles in front of its sphere hit.
+                    // (The pass over hits that shades this ray's hit makes the same test again to know which tree it was.)
                     PT_FRESH_PARAMS(LG);
-                    if (LG.sc.guard_on != 0u && (hid & PT_ID_TIE) == 0u && pt_guard_in_reach(LG.sc, wray.o, wray.d)) {
+                    if (LG.sc.guard_on != 0u && pt_ray_walks_guard(LG.sc, wray.o, wray.d, sh.st[F_FS][p])) {
                         w.node = LG.sc.guard_root;
                         w.sp = 0;
                         w.leaf_left = 0;
                         if (w.rec.hit) w.nearest = pt_min(9999.0f, w.rec.t);
-                        wsteps = PT_STEPS_GUARD;
                         cn.guarded++;
                     }
                 }
@@ -1642,23 +1648,20 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
 #endif
                     if (wbusy) {
                         wsteps++;
-                        bool tie;
-                        const bool over = walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last, tie);
-                        wsteps |= tie ? PT_STEPS_TIE : 0u;
-                        if (over) {
+                        if (walk_consume<STATS>(sc, wray.o, wray.d, w, have, stack, cn, next, !last)) {
                             const uint32_t p = wpath;
                             sh.st[F_T][p] = __float_as_uint(w.rec.t);
-                            sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | ((wsteps & (PT_STEPS_GUARD | PT_STEPS_TIE)) >> 2) | w.rec.index;
+                            sh.st[F_ID][p] = (w.rec.hit ? 0x80000000u : 0u) | (w.rec.is_tri ? 0x40000000u : 0u) | w.rec.index;  // (PT_ID_TIE rides on the index)
                             sh.st[F_U][p] = __float_as_uint(w.rec.u);
                             sh.st[F_V][p] = __float_as_uint(w.rec.v);
-                            sh.st[F_COST][p] += wsteps & PT_STEPS_COUNT;
+                            sh.st[F_COST][p] += wsteps;
                             wbusy = false;
                             fin = true;
                         }
                     }
 #ifdef PT_DIAG
                     {
-                        const uint32_t ws = wsteps & PT_STEPS_COUNT;
+                        const uint32_t ws = wsteps;
                         const bool ended = fin && !wbusy && ws != 0u;
                         const uint32_t b = ws <= 1u ? 0 : ws <= 2u ? 1 : ws <= 4u ? 2 : ws <= 8u ? 3 : ws <= 16u ? 4 : ws <= 32u ? 5 : ws <= 64u ? 6 : 7;
                         for (uint32_t q = 0; q < 8u; q++) {
@@ -1743,7 +1746,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 const uint32_t fs = sh.st[F_FS][p];
                 const bool had_ray = HITS || (fs & 1u) != 0;
                 bool want_aov = (fs & 2u) != 0;
-                uint32_t sample = fs >> 2;
+                uint32_t sample = fs >> 3;
                 uint32_t frame = sh.st[F_FRAME][p];
                 uint32_t bounce = 0, limit = depth;
                 v3 color = V3(1.0f, 1.0f, 1.0f), initial_d = V3(0.0f, 0.0f, 0.0f);
@@ -1754,10 +1757,33 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                 bool rewalk = false;                     // the ray in hand is not shaded: it walks the reference tree first
                 v3 path_color = V3(0.0f, 0.0f, 0.0f);    // its colour (a miss: still to be multiplied by the sky texel)
                 v3 sky = V3(1.0f, 1.0f, 1.0f);
+                Closest c;
+                c.hit = c.is_tri = false;
+                c.index = 0;
+                c.t = c.u = c.v = 0.0f;
+                if constexpr (HITS) {
+                    cur.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
+                    cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
+                    const uint32_t hid = sh.st[F_ID][p];
+                    c.hit = true;
+                    c.is_tri = ((hid >> 30) & 1u) != 0;
+                    c.index = hid & PT_ID_INDEX;
+                    c.t = __uint_as_float(sh.st[F_T][p]);
+                    c.u = __uint_as_float(sh.st[F_U][p]);
+                    c.v = __uint_as_float(sh.st[F_V][p]);
+                    // A triangle found on the guard tree counts only if the reference walk is certain to return the same one;
+                    // otherwise the same ray walks the reference tree (nothing of the path has changed yet).  (A stage of its
+                    // own, so that its scalars are gone before the shading's are loaded.)
+                    if constexpr (!STATS) {
+                        PT_FRESH_PARAMS(LG);
+                        if (LG.sc.guard_on != 0u)
+                            rewalk = c.is_tri && pt_ray_walks_guard(LG.sc, cur.o, cur.d, fs) && ((hid & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(LG.sc, cur, c));
+                    }
+                }
                 if (had_ray) {
                     PT_FRESH_PARAMS(L);
                     const PtDeviceScene &sc = L.sc;
-                    cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
+                    if constexpr (!HITS) cur.d = V3(__uint_as_float(sh.st[F_DX][p]), __uint_as_float(sh.st[F_DY][p]), __uint_as_float(sh.st[F_DZ][p]));
                     color = V3(__uint_as_float(sh.st[F_COLR][p]), __uint_as_float(sh.st[F_COLG][p]), __uint_as_float(sh.st[F_COLB][p]));
                     if constexpr (!HITS) {
                         // compute.wgsl:140-143
@@ -1771,24 +1797,12 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                             want_aov = false;
                         }
                     } else {
-                        cur.o = V3(__uint_as_float(sh.st[F_OX][p]), __uint_as_float(sh.st[F_OY][p]), __uint_as_float(sh.st[F_OZ][p]));
-                        Closest c;
-                        const uint32_t hid = sh.st[F_ID][p];
-                        c.hit = true;
-                        c.is_tri = ((hid >> 30) & 1u) != 0;
-                        c.index = hid & PT_ID_INDEX;
-                        c.t = __uint_as_float(sh.st[F_T][p]);
-                        c.u = __uint_as_float(sh.st[F_U][p]);
-                        c.v = __uint_as_float(sh.st[F_V][p]);
                         seed = __uint_as_float(sh.st[F_SEED][p]);
                         bounce = sh.st[F_BOUNCE][p];
                         if constexpr (GIZMO) {
                             initial_d = V3(__uint_as_float(sh.st[FL::IDIR][p]), __uint_as_float(sh.st[FL::IDIR + 1][p]), __uint_as_float(sh.st[FL::IDIR + 2][p]));
                             limit = sh.st[FL::LIMIT][p];
                         }
-                        // A triangle found on the guard tree counts only if the reference walk is certain to return the same
-                        // one; otherwise the same ray walks the reference tree (nothing of the path has changed yet).
-                        if constexpr (!STATS) rewalk = c.is_tri && (hid & PT_ID_GUARD) != 0u && ((hid & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(sc, cur, c));
                         if (!rewalk) {
                             uint32_t prim;
                             v3 result = V3(0.0f, 0.0f, 0.0f);
@@ -1832,7 +1846,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     // without a ray is one of theirs), where every lane starts a path, instead of here, where the few lanes
                     // that retire would have the whole wave run the RNG and the camera ray.
                     sh.st[F_FRAME][p] = frame;
-                    sh.st[F_FS][p] = sample << 2;
+                    sh.st[F_FS][p] = sample << 3;
                     sh.st[F_COST][p] = cost;
                     to_ready = true;
                 } else {
@@ -1878,14 +1892,14 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     sh.st[F_OX][p] = __float_as_uint(cur.o.x); sh.st[F_OY][p] = __float_as_uint(cur.o.y); sh.st[F_OZ][p] = __float_as_uint(cur.o.z);
                     sh.st[F_DX][p] = __float_as_uint(cur.d.x); sh.st[F_DY][p] = __float_as_uint(cur.d.y); sh.st[F_DZ][p] = __float_as_uint(cur.d.z);
                     sh.st[F_T][p] = __float_as_uint(nw.rec.t);
-                    sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | (rewalk ? PT_ID_TIE : 0u) | nw.rec.index;  // (in a pending slot: reference tree only)
+                    sh.st[F_ID][p] = (nw.rec.hit ? 0x80000000u : 0u) | nw.rec.index;
                     sh.st[F_U][p] = need_walk ? nw.node : 0u;
                     sh.st[F_V][p] = need_walk ? k2 : 0u;
                     sh.st[F_COLR][p] = __float_as_uint(color.x); sh.st[F_COLG][p] = __float_as_uint(color.y); sh.st[F_COLB][p] = __float_as_uint(color.z);
                     sh.st[F_SEED][p] = __float_as_uint(seed);
                     sh.st[F_BOUNCE][p] = bounce;
                     sh.st[F_FRAME][p] = frame;
-                    sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
+                    sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (rewalk ? 4u : 0u) | (sample << 3);
                     sh.st[F_COST][p] = cost;
                     if constexpr (GIZMO) {
                         sh.st[FL::IDIR][p] = __float_as_uint(initial_d.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(initial_d.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(initial_d.z);
@@ -1954,7 +1968,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                     const uint32_t fs = sh.st[F_FS][p];
                     have_ray = (fs & 1u) != 0;
                     want_aov = (fs & 2u) != 0;
-                    sample = fs >> 2;
+                    sample = fs >> 3;
                     frame = sh.st[F_FRAME][p];
                     cost = sh.st[F_COST][p];
                     if (have_ray) {
@@ -2095,7 +2109,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                                 sh.st[F_SEED][p] = __float_as_uint(seed);
                                 sh.st[F_BOUNCE][p] = lbounce;
                                 sh.st[F_FRAME][p] = frame;
-                                sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 2);
+                                sh.st[F_FS][p] = 1u | (want_aov ? 2u : 0u) | (sample << 3);
                                 sh.st[F_COST][p] = cost;
                                 if constexpr (GIZMO) {
                                     sh.st[FL::IDIR][p] = __float_as_uint(lidir.x); sh.st[FL::IDIR + 1][p] = __float_as_uint(lidir.y); sh.st[FL::IDIR + 2][p] = __float_as_uint(lidir.z);
@@ -2136,7 +2150,7 @@ __global__ __launch_bounds__(PT_PP_THREADS, PT_PP_WAVES_PER_EU) void pool_kernel
                         sh.st[F_DX][p] = __float_as_uint(d.x); sh.st[F_DY][p] = __float_as_uint(d.y); sh.st[F_DZ][p] = __float_as_uint(d.z);
                         sh.st[F_COLR][p] = __float_as_uint(color.x); sh.st[F_COLG][p] = __float_as_uint(color.y); sh.st[F_COLB][p] = __float_as_uint(color.z);
                         sh.st[F_FRAME][p] = frame;
-                        sh.st[F_FS][p] = (have_ray ? 1u : 0u) | (want_aov ? 2u : 0u) | (sample << 2);
+                        sh.st[F_FS][p] = (have_ray ? 1u : 0u) | (want_aov ? 2u : 0u) | (sample << 3);
                         sh.st[F_COST][p] = cost;
                         if constexpr (!SPP1) { sh.st[FL::RNG][p] = rx; sh.st[FL::RNG + 1][p] = ry; sh.st[FL::RNG + 2][p] = rz; sh.st[FL::RNG + 3][p] = rw; }
                         to_ready = true;
@@ -2261,10 +2275,9 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
         w.node = Q.sc.guard_root;
         w.sp = 0;
         w.inv = pt_rcp3(r.d);
-        bool tie = false;
-        while (!walk_step<false>(Q.sc, r, w, stack, cn, &tie)) {}
+        while (!walk_step<false>(Q.sc, r, w, stack, cn)) {}
         c = w.rec;
-        settled = !(c.hit && c.is_tri) || (!tie && pt_guard_hit_is_certain(Q.sc, r, c));
+        settled = !(c.hit && c.is_tri) || ((c.index & PT_ID_TIE) == 0u && pt_guard_hit_is_certain(Q.sc, r, c));
         if (Q.walked) Q.walked[i] = settled ? 1u : 2u;
     } else if (Q.walked) {
         Q.walked[i] = 0u;

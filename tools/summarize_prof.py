@@ -69,7 +69,7 @@ if vals["FETCH_SIZE"] is not None and vals["WRITE_SIZE"] is not None:
     args = sys.argv[2:]
     frames = int(args[args.index("--frames") + 1]) if "--frames" in args else 256
     workload = args[args.index("--workload") + 1] if "--workload" in args else "bunny_1080p_d8_spp256"
-    rec = {"workload": workload, "frames": frames, "bvh": "sah" if "--rebuild-bvh" in args else "reference",
+    rec = {"workload": workload, "frames": frames, "bvh": "sah" if "--rebuild-bvh" in args else "reference-walk-only" if "--reference-walk" in args else "reference",
            "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
            "hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0,
            "kernels": "megakernel + sky_tiles_kernel + accumulate_kernel of one planned launch",
