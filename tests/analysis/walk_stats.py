@@ -2,9 +2,12 @@
 scene's rays, bounce level by bounce level, and what is the chain of dependent steps that bounds a single frame --
 (a) for a scheduler that ties a tile's 64 pixels together bounce level by bounce level (sum over levels of the tile's
 longest walk), (b) for one that lets every path run on its own (the longest single path)?  Optionally with another tree
-over the same triangles (--sah: the library's binned-SAH builder, if it has one) to see what a better tree would save.
+over the same triangles (--sah: the library's binned-SAH builder, if it has one) to see what a better tree would save,
+and with that builder's tree over padded triangle bounds (--second-tree: the padding restated here from pt_set_mesh's
+plan_guard -- 48 * 2^-24 * 1e5 * |e1| |e2| * reach, reach = 8 * (mesh radius + longest edge) -- to see what the tree
+that the megakernels walk by default costs over the unpadded one).
 
-Usage: python tests/analysis/walk_stats.py [--depth 16] [--width 1920 --height 1080] [--time 100] [--n 76] [--sah] [--field]"""
+Usage: python tests/analysis/walk_stats.py [--depth 16] [--width 1920 --height 1080] [--time 100] [--n 76] [--sah] [--second-tree] [--field]"""
 import argparse
 import ctypes as C
 import importlib
@@ -36,6 +39,7 @@ def main():
     ap.add_argument("--time", type=int, default=100)
     ap.add_argument("--n", type=int, default=76)
     ap.add_argument("--sah", action="store_true")
+    ap.add_argument("--second-tree", action="store_true")
     ap.add_argument("--field", action="store_true")
     a = ap.parse_args()
     import _pkgload
@@ -52,6 +56,19 @@ def main():
         nodes, idx = pt.bvh_build_sah(scene.triangles)
         trees.append(("binned SAH", po.OracleScene(a.width, a.height, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres),
                                                    scene.triangles, nodes, idx, sky, 0)))
+    if a.second_tree:
+        tr = scene.triangles
+        A, B, Cc = (tr[k].astype(np.float64) for k in ("a", "b", "c"))
+        e1, e2, e3 = np.linalg.norm(B - A, axis=1), np.linalg.norm(Cc - A, axis=1), np.linalg.norm(Cc - B, axis=1)
+        allv = np.concatenate([A, B, Cc])
+        centre = 0.5 * (allv.min(0) + allv.max(0))
+        reach = 8.0 * (np.linalg.norm(allv - centre, axis=1).max() + max(e1.max(), e2.max(), e3.max()))
+        pad = 48.0 * 2.0 ** -24 * 1e5 * reach * e1 * e2 + 8.0 * 2.0 ** -24 * (np.abs(allv).max() + 2.0 * reach + np.abs(centre).max())
+        print(f"second tree: reach {reach:.3f}, padding median {np.median(pad):.2e}, max {pad.max():.2e}; triangle extent median "
+              f"{np.median((np.maximum(np.maximum(A, B), Cc) - np.minimum(np.minimum(A, B), Cc)).max(1)):.2e}")
+        nodes, idx = pt.bvh_build_sah(tr, pad=pad.astype(np.float32))
+        trees.append(("binned SAH over padded bounds (the megakernels' second tree)",
+                      po.OracleScene(a.width, a.height, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), tr, nodes, idx, sky, 0)))
     for name, o in trees:
         out = np.zeros((a.height, a.width, LEVELS), np.uint16)
         acc = np.zeros((a.height, a.width, 4), np.float32)
