@@ -58,7 +58,7 @@ struct pt_ctx {
     // the guard tree (PtDeviceScene::guard_on ...), if pt_set_mesh built one
     bool guard_on = false;
     float guard_center[3] = {}, guard_radius = 0.0f, guard_reach = 0.0f, guard_margin = 0.0f;
-    uint32_t guard_root = 0, guard_nodes = 0, guard_depth = 0;
+    uint32_t guard_root = 0, guard_nodes = 0, guard_depth = 0, guard_quads = 0;
     float guard_pad_median = 0.0f;
 
     float4 *sky = nullptr;
@@ -278,6 +278,7 @@ void free_mesh(pt_ctx *ctx)
     ctx->walk_depth = 0;
     ctx->guard_on = false;
     ctx->guard_nodes = ctx->guard_depth = 0;
+    ctx->guard_quads = 0;
 }
 
 PtDeviceScene device_scene(const pt_ctx *ctx)
@@ -303,6 +304,7 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.guard_reach = ctx->guard_reach;
     sc.guard_margin = ctx->guard_margin;
     sc.guard_root = ctx->guard_root;
+    sc.guard_quads = ctx->guard_quads;
     return sc;
 }
 
@@ -721,6 +723,9 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     // tree's (slots n_idx ..), its pairs behind those -- guard node j at unit guard_first_unit + j + 1, so that pairs
     // (odd, even) are aligned like the reference tree's.
     GuardPlan gp;
+    std::vector<uint32_t> quad_nodes, quad_children, quad_of;  // per record: the node it stands for, its (up to) four children; per node: its record
+    uint64_t quad_first_unit = 0;
+    uint32_t q_depth = 0;
     std::vector<PtNode> g_nodes;
     std::vector<uint32_t> g_idx;
     uint32_t n_gnodes = 0, g_depth = 0;
@@ -751,6 +756,44 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
             if (g_depth > PT_MAX_BVH_DEPTH) gp.on = false;
         }
         if (gp.on) table_units = guard_first_unit + 2 * (uint64_t)n_tris + (((uint64_t)n_gnodes + 2) & ~1ull);
+        // The same tree with four children to a record (PtDeviceScene::guard_quads): every interior node takes its two
+        // children and, as long as it has fewer than four, replaces the largest interior one of them by that one's two.
+        if (gp.on) {
+            auto half_area = [&](uint32_t i) {
+                const PtNode &n = g_nodes[i];
+                const double dx = (double)n.max_corner[0] - n.min_corner[0], dy = (double)n.max_corner[1] - n.min_corner[1], dz = (double)n.max_corner[2] - n.min_corner[2];
+                return dx * dy + dy * dz + dz * dx;
+            };
+            quad_of.assign(n_gnodes, 0xFFFFFFFFu);
+            quad_nodes.push_back(0);
+            quad_of[0] = 0;
+            std::vector<uint32_t> qdepth{0};
+            for (size_t qi = 0; qi < quad_nodes.size(); qi++) {
+                const PtNode &n = g_nodes[quad_nodes[qi]];
+                uint32_t ch[4] = {n.left_child_index, n.left_child_index + 1u, 0, 0}, nch = 2;
+                while (nch < 4u) {
+                    int best = -1;
+                    double best_area = -1.0;
+                    for (uint32_t c = 0; c < nch; c++)
+                        if (g_nodes[ch[c]].triangle_count == 0 && half_area(ch[c]) > best_area) { best = (int)c; best_area = half_area(ch[c]); }
+                    if (best < 0) break;
+                    const uint32_t l = g_nodes[ch[best]].left_child_index;
+                    ch[best] = l;
+                    ch[nch++] = l + 1u;
+                }
+                for (uint32_t c = 0; c < 4u; c++) quad_children.push_back(c < nch ? ch[c] : 0xFFFFFFFFu);
+                for (uint32_t c = 0; c < nch; c++)
+                    if (g_nodes[ch[c]].triangle_count == 0) {
+                        quad_of[ch[c]] = (uint32_t)quad_nodes.size();
+                        quad_nodes.push_back(ch[c]);
+                        qdepth.push_back(qdepth[qi] + 1u);
+                        q_depth = std::max(q_depth, qdepth[qi] + 1u);
+                    }
+            }
+            quad_first_unit = table_units;  // (even)
+            if (quad_first_unit + 2 * (uint64_t)quad_nodes.size() > (1ull << 27) || 3u * (q_depth + 1u) + 1u > PT_MAX_BVH_DEPTH) quad_nodes.clear();  // no room: the pair form alone
+            else table_units = quad_first_unit + 2 * (uint64_t)quad_nodes.size();
+        }
     }
     const uint64_t guard_node_unit = guard_first_unit + 2 * (uint64_t)n_tris;  // (even) guard node j lives at unit guard_node_unit + j + 1
     const uint32_t n_slots = n_idx + (gp.on ? n_tris : 0u);
@@ -805,6 +848,47 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
             rec[2] = make_float4(a.max_corner[1], b.max_corner[1], a.max_corner[2], b.max_corner[2]);
             rec[3] = make_float4(u2f(guard_token(n.left_child_index)), u2f(guard_token(n.left_child_index + 1)), 0.0f, 0.0f);
         }
+        for (size_t qi = 0; qi < quad_nodes.size(); qi++) {
+            const uint32_t *ch = &quad_children[4 * qi];
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t c = 0; c < 4u && ch[c] != 0xFFFFFFFFu; c++)
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = std::min(lo[a], (double)g_nodes[ch[c]].min_corner[a]);
+                    hi[a] = std::max(hi[a], (double)g_nodes[ch[c]].max_corner[a]);
+                }
+            float org[3], scale[3];
+            uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; a++) {
+                org[a] = (float)lo[a];  // (the children's corners are floats: exact)
+                int e = -126;
+                if (hi[a] > lo[a]) e = std::max(-126, (int)std::ceil(std::log2((hi[a] - lo[a]) / 255.0)));
+                while (std::ldexp(255.0, e) < hi[a] - lo[a]) e++;
+                scale[a] = (float)std::ldexp(1.0, e);
+                for (uint32_t c = 0; c < 4u; c++) {
+                    uint32_t bl = 0, bh = 0;  // (an absent child: its token says so)
+                    if (ch[c] != 0xFFFFFFFFu) {
+                        const double l = ((double)g_nodes[ch[c]].min_corner[a] - lo[a]) / scale[a], h = ((double)g_nodes[ch[c]].max_corner[a] - lo[a]) / scale[a];
+                        bl = (uint32_t)std::min(255.0, std::max(0.0, std::floor(l)));
+                        bh = (uint32_t)std::min(255.0, std::max(0.0, std::ceil(h)));
+                        // (origin + byte * scale is exact in double; the box may only grow)
+                        if (lo[a] + bl * (double)scale[a] > (double)g_nodes[ch[c]].min_corner[a] || lo[a] + bh * (double)scale[a] < (double)g_nodes[ch[c]].max_corner[a])
+                            return fail(ctx, PT_ERR_INTERNAL, "pt_set_mesh: a quantised box of the second tree does not contain its node");
+                    }
+                    qlo[a] |= bl << (8u * c);
+                    qhi[a] |= bh << (8u * c);
+                }
+            }
+            auto quad_token = [&](uint32_t i) -> uint32_t {
+                if (i == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+                if (g_nodes[i].triangle_count == 0) return (uint32_t)(quad_first_unit - 1u) + 2u * quad_of[i];
+                return guard_token(i);
+            };
+            float4 *rec = &h_nodes[2 * (quad_first_unit + 2 * qi)];
+            rec[0] = make_float4(org[0], org[1], org[2], scale[0]);
+            rec[1] = make_float4(u2f(qlo[0]), u2f(qlo[1]), u2f(qlo[2]), u2f(qhi[0]));
+            rec[2] = make_float4(u2f(qhi[1]), u2f(qhi[2]), u2f(quad_token(ch[0])), u2f(quad_token(ch[1])));
+            rec[3] = make_float4(u2f(quad_token(ch[2])), u2f(quad_token(ch[3])), scale[1], scale[2]);
+        }
     }
 
     free_mesh(ctx);
@@ -825,7 +909,8 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     if (nodes[0].triangle_count == 0)
         for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
     ctx->bvh_depth = max_depth;
-    ctx->walk_depth = std::max(max_depth, gp.on ? g_depth : 0u);
+    // (a walk of the four-child form pushes up to three entries per level)
+    ctx->walk_depth = std::max(max_depth, gp.on ? std::max(g_depth, quad_nodes.empty() ? 0u : 3u * (q_depth + 1u) + 1u) : 0u);
     ctx->guard_on = gp.on;
     if (gp.on) {
         for (int k = 0; k < 3; k++) ctx->guard_center[k] = gp.center[k];
@@ -833,6 +918,8 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
         ctx->guard_reach = gp.reach;
         ctx->guard_margin = gp.margin;
         ctx->guard_root = (uint32_t)guard_node_unit + g_nodes[0].left_child_index;
+        ctx->guard_quads = quad_nodes.empty() ? 0u : (uint32_t)(quad_first_unit - 1u);
+        if (env_str("PTRT_NO_QUADS")) ctx->guard_quads = 0;  // (tuning builds: the pair form everywhere)
         ctx->guard_nodes = n_gnodes;
         ctx->guard_depth = g_depth;
         ctx->guard_pad_median = gp.pad_median;

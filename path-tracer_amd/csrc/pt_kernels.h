@@ -90,6 +90,13 @@ struct PtDeviceScene {
     // walks the reference tree.
     uint32_t guard_on;
     uint32_t guard_root;     // table position of the pair of the guard root's children (the guard root is always interior)
+    // The guard tree once more, four children to a 64-byte record (the kernels that step one ray per lane walk this form:
+    // half as many dependent fetches per walk).  Record j at position guard_quads + 2 j, j = 0 the root:
+    //   {origin.x, origin.y, origin.z, scale.x} {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, token 0, token 1} {token 2, token 3,
+    //   scale.y, scale.z} -- lo / hi: one byte per child, bounds = origin + byte * scale (scale a power of two, lo rounded
+    //   down, hi up: a box never shrinks); a token is a leaf token of the pair form, the position of another record, or
+    //   0xFFFFFFFF (no child).  0: no such records.
+    uint32_t guard_quads;
     float guard_center[3];   // centre of the mesh's bounds
     float guard_radius;      // no vertex is further from the centre than this (longest edge included)
     float guard_reach;       // (|origin - centre| + radius) * max(1, |direction|) at most this: the ray may walk the guard tree

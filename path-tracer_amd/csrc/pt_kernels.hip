@@ -370,6 +370,46 @@ __device__ __forceinline__ void walk_enter(WalkU &w)
     }
 }
 
+// One visit of a four-child record of the guard tree (PtDeviceScene::guard_quads) loaded into q0..q3: the four slab
+// tests on bounds dequantised on the fly -- t = byte * (scale / d) + (origin - o) / d per plane, which is the slab test of
+// compute.wgsl:441-456 on the box origin + byte * scale up to a rounding that the guard tree's padding covers --, the
+// children sorted by entry distance, the nearest entered and the others pushed farthest first.  Which order the children
+// are visited in is free here: the guard walk only has to reach every box that a hit may lie in.
+template <typename StackT>
+__device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 q1, float4 q2, float4 q3, WalkU &w, StackT stack, bool &next_node)
+{
+    const float ax = q0.w * inv.x, ay = q3.z * inv.y, az = q3.w * inv.z;
+    const float bx = (q0.x - o.x) * inv.x, by = (q0.y - o.y) * inv.y, bz = (q0.z - o.z) * inv.z;
+    const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+    const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    uint32_t k[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
+    float dist[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        const float tlx = pt_fma((float)((lox >> (8u * c)) & 0xFFu), ax, bx), thx = pt_fma((float)((hix >> (8u * c)) & 0xFFu), ax, bx);
+        const float tly = pt_fma((float)((loy >> (8u * c)) & 0xFFu), ay, by), thy = pt_fma((float)((hiy >> (8u * c)) & 0xFFu), ay, by);
+        const float tlz = pt_fma((float)((loz >> (8u * c)) & 0xFFu), az, bz), thz = pt_fma((float)((hiz >> (8u * c)) & 0xFFu), az, bz);
+        const float tmin = pt_max(pt_max(pt_min(tlx, thx), pt_min(tly, thy)), pt_min(tlz, thz));
+        const float tmax = pt_min(pt_min(pt_max(tlx, thx), pt_max(tly, thy)), pt_max(tlz, thz));
+        dist[c] = (tmin > tmax || tmax < 0.0f || k[c] == 0xFFFFFFFFu) ? 99999.0f : tmin;
+    }
+    auto order = [&](uint32_t i, uint32_t j) {  // (dist[i], k[i]) <= (dist[j], k[j]) afterwards
+        const bool swap = dist[i] > dist[j];
+        const float dn = swap ? dist[j] : dist[i], df = swap ? dist[i] : dist[j];
+        const uint32_t kn = swap ? k[j] : k[i], kf = swap ? k[i] : k[j];
+        dist[i] = dn; dist[j] = df; k[i] = kn; k[j] = kf;
+    };
+    order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+    if (dist[0] > w.nearest) {
+        next_node = true;
+    } else {
+        w.node = k[0];
+        if (dist[3] < w.nearest) stack.push(w.sp++, k[3]);
+        if (dist[2] < w.nearest) stack.push(w.sp++, k[2]);
+        if (dist[1] < w.nearest) stack.push(w.sp++, k[1]);
+    }
+}
+
 template <bool STATS, typename StackT>
 __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn)
 {
@@ -389,7 +429,9 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         // (the empty asm uses the values here, so the compiler cannot sink part of the loads into the
         // interior-node branch, where they would cost that branch a second wait)
         asm volatile("" : : "v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.x), "v"(q3.y));
-        if (!tri) {
+        if (!tri && !STATS && sc.guard_quads != 0u && w.node >= sc.guard_quads) {
+            walk_quad_visit(o, w.inv, q0, q1, q2, q3, w, stack, next_node);
+        } else if (!tri) {
             if (STATS) cn.interior++;
             float d1, d2;
             hit_aabb_pair(o, w.inv, q0, q1, q2, d1, d2);
@@ -1020,7 +1062,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                         if (mode == M_WALK && !redo && L.sc.guard_on != 0u && pt_guard_in_reach(L.sc, cur.o, cur.d)) {
                             on_guard = true;
                             cn.guarded++;
-                            w.node = L.sc.guard_root;
+                            w.node = L.sc.guard_quads != 0u ? L.sc.guard_quads : L.sc.guard_root;
                             w.sp = 0;
                             if (w.rec.hit) w.nearest = pt_min(9999.0f, w.rec.t);
                         }
@@ -2260,30 +2302,41 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     r.d = V3(Q.dirs[3 * i], Q.dirs[3 * i + 1], Q.dirs[3 * i + 2]);
     Counters cn;
 #ifdef PT_TUNING
-    // (tuning builds: the ray's traversal steps ride in the upper bits of `front`, for tools/step_latency.py)
-    const Closest c = hit_scene<true>(Q.sc, r, stack, cn);
+    // (tuning builds: the ray's traversal steps ride in the upper bits of `front`, for tools/step_latency.py, and the walk
+    // is the reference tree's unless `walked` is asked for: tools/guard_steps.py)
+    constexpr bool count_steps = true;
+    const bool try_guard = Q.walked != nullptr;
 #else
+    constexpr bool count_steps = false;
+    const bool try_guard = true;
+#endif
     // Where the mesh has a guard tree, the pooled kernel's scheme, ray by ray: a ray in reach walks the guard tree, a
     // triangle found there counts if it is certain to be the reference walk's as well, and everything else walks the
     // reference tree.  (This is also how that scheme is tested on rays aimed at edges, vertices and grazing angles.)
     Closest c;
     bool settled = false;
-    if (Q.sc.guard_on != 0u && pt_guard_in_reach(Q.sc, r.o, r.d)) {
-        Walk w;
+    if (try_guard && Q.sc.guard_on != 0u && pt_guard_in_reach(Q.sc, r.o, r.d)) {
+        WalkU w;
         w.rec = hit_spheres<false>(Q.sc, r.o, r.d, cn);
         w.nearest = w.rec.hit ? pt_min(9999.0f, w.rec.t) : 9999.0f;
-        w.node = Q.sc.guard_root;
+        w.node = Q.sc.guard_quads != 0u ? Q.sc.guard_quads : Q.sc.guard_root;
         w.sp = 0;
+        w.leaf_left = 0;
+        w.top = 0;
         w.inv = pt_rcp3(r.d);
-        while (!walk_step<false>(Q.sc, r, w, stack, cn)) {}
+        uint32_t trips = 1;
+        while (!walk_step_u<false>(Q.sc, r, w, stack, cn)) trips++;
         c = w.rec;
         settled = !(c.hit && c.is_tri) || ((c.index & PT_ID_TIE) == 0u && pt_guard_hit_is_certain(Q.sc, r, c));
+#ifdef PT_TUNING
+        if (Q.walked) Q.walked[i] = (settled ? 1u : 2u) | (trips << 2);  // (tuning builds: the guard walk's steps ride along)
+#else
         if (Q.walked) Q.walked[i] = settled ? 1u : 2u;
+#endif
     } else if (Q.walked) {
         Q.walked[i] = 0u;
     }
-    if (!settled) c = hit_scene<false>(Q.sc, r, stack, cn);
-#endif
+    if (!settled) c = hit_scene<count_steps>(Q.sc, r, stack, cn);
     const HitRecord h = make_record(Q.sc, r, c);
     if (Q.prim) Q.prim[i] = h.prim;
     if (Q.t) Q.t[i] = h.t;
