@@ -384,14 +384,20 @@ __device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 
     const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
     uint32_t k[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
     float dist[4];
+    // (two children at a time: the twelve multiply-adds of a pair of children are six two-wide packed instructions)
+    const pt_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
 #pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        const float tlx = pt_fma((float)((lox >> (8u * c)) & 0xFFu), ax, bx), thx = pt_fma((float)((hix >> (8u * c)) & 0xFFu), ax, bx);
-        const float tly = pt_fma((float)((loy >> (8u * c)) & 0xFFu), ay, by), thy = pt_fma((float)((hiy >> (8u * c)) & 0xFFu), ay, by);
-        const float tlz = pt_fma((float)((loz >> (8u * c)) & 0xFFu), az, bz), thz = pt_fma((float)((hiz >> (8u * c)) & 0xFFu), az, bz);
-        const float tmin = pt_max(pt_max(pt_min(tlx, thx), pt_min(tly, thy)), pt_min(tlz, thz));
-        const float tmax = pt_min(pt_min(pt_max(tlx, thx), pt_max(tly, thy)), pt_max(tlz, thz));
-        dist[c] = (tmin > tmax || tmax < 0.0f || k[c] == 0xFFFFFFFFu) ? 99999.0f : tmin;
+    for (uint32_t c = 0; c < 4u; c += 2u) {
+        auto two = [&](uint32_t word) { return pt_f2{(float)((word >> (8u * c)) & 0xFFu), (float)((word >> (8u * c + 8u)) & 0xFFu)}; };
+        const pt_f2 tlx = __builtin_elementwise_fma(two(lox), ax2, bx2), thx = __builtin_elementwise_fma(two(hix), ax2, bx2);
+        const pt_f2 tly = __builtin_elementwise_fma(two(loy), ay2, by2), thy = __builtin_elementwise_fma(two(hiy), ay2, by2);
+        const pt_f2 tlz = __builtin_elementwise_fma(two(loz), az2, bz2), thz = __builtin_elementwise_fma(two(hiz), az2, bz2);
+        const float tmin0 = pt_max(pt_max(pt_min(tlx.x, thx.x), pt_min(tly.x, thy.x)), pt_min(tlz.x, thz.x));
+        const float tmax0 = pt_min(pt_min(pt_max(tlx.x, thx.x), pt_max(tly.x, thy.x)), pt_max(tlz.x, thz.x));
+        const float tmin1 = pt_max(pt_max(pt_min(tlx.y, thx.y), pt_min(tly.y, thy.y)), pt_min(tlz.y, thz.y));
+        const float tmax1 = pt_min(pt_min(pt_max(tlx.y, thx.y), pt_max(tly.y, thy.y)), pt_max(tlz.y, thz.y));
+        dist[c] = (tmin0 > tmax0 || tmax0 < 0.0f || k[c] == 0xFFFFFFFFu) ? 99999.0f : tmin0;
+        dist[c + 1u] = (tmin1 > tmax1 || tmax1 < 0.0f || k[c + 1u] == 0xFFFFFFFFu) ? 99999.0f : tmin1;
     }
     auto order = [&](uint32_t i, uint32_t j) {  // (dist[i], k[i]) <= (dist[j], k[j]) afterwards
         const bool swap = dist[i] > dist[j];
