@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -43,7 +44,12 @@ struct Box {
 
 constexpr int kBins = 16;         // (32 bins, leaves of 2 or 8, a node visit priced at 0.5 to 2 triangle tests: all within 2 % in steps per ray)
 constexpr int kBinsMax = kBins;
+#ifdef PT_TUNING
+static uint32_t tuned_leaf() { const char *e = getenv("PTRT_GUARD_LEAF"); return e ? (uint32_t)atoi(e) : 4u; }
+static const uint32_t kMaxLeaf = tuned_leaf();  // (tuning builds: leaf size of every tree this builder makes)
+#else
 constexpr uint32_t kMaxLeaf = 4;
+#endif
 constexpr float kTrav = 1.0f;
 
 struct SahBuilder {

@@ -137,6 +137,22 @@ int main()
             std::printf("bvh round %d: the SAH builder's tree is malformed (%lld nodes)\n", round, (long long)us);
             return 4;
         }
+        // ... and over padded bounds (hostile pads too: huge, infinite, NaN)
+        std::vector<float> pad(n);
+        for (float &p : pad) p = 0.01f * (float)(rng() % 100);
+        if (n > 10) { pad[rng() % n] = 3.0e38f; pad[rng() % n] = INFINITY; pad[rng() % n] = NAN; }
+        const int64_t up = pt_bvh_build_sah_padded(tris.data(), n, pad.data(), ns.data(), is.data());
+        std::fill(seen.begin(), seen.end(), 0);
+        good = up >= 1 && up <= 2 * (int64_t)n - 1;
+        for (uint32_t k = 0; good && k < n; k++) { good = is[k] < n && !seen[is[k]]; if (good) seen[is[k]] = 1; }
+        for (int64_t k = 0; good && k < up; k++) {
+            if (ns[k].triangle_count == 0) good = ns[k].left_child_index > k && (int64_t)ns[k].left_child_index + 1 < up;
+            else good = (uint64_t)ns[k].left_child_index + ns[k].triangle_count <= n;
+        }
+        if (!good) {
+            std::printf("bvh round %d: the padded SAH builder's tree is malformed (%lld nodes)\n", round, (long long)up);
+            return 5;
+        }
     }
     std::printf("bvh: thread counts agree\nok\n");
     return 0;

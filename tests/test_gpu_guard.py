@@ -208,3 +208,26 @@ def test_rays_aimed_at_edges_vertices_and_grazing_angles(pt, po, scenes):
     assert not rwalked.any() and np.array_equal(rp, gp) and np.array_equal(rt.view(np.uint32), gt.view(np.uint32))
     r.close()
     r2.close()
+
+
+def test_callers_tree_with_boxes_that_do_not_contain_their_triangles(pt, po, scenes):
+    """The check that certifies a hit leans on the caller's boxes containing what is below them.  A caller's tree whose
+    boxes are too small is still a tree the shader would walk (missing what its boxes hide): no second tree is built
+    for it, and the picture is the oracle's walk of those very nodes."""
+    scene = scenes.bunny(n=32)
+    nodes = scene.nodes.copy()
+    mid = 0.5 * (nodes["min"] + nodes["max"])
+    nodes["min"] = (mid + 0.9 * (nodes["min"] - mid)).astype(np.float32)
+    nodes["max"] = (mid + 0.9 * (nodes["max"] - mid)).astype(np.float32)
+    scene.nodes = nodes
+    w, h, st, sky = 160, 96, pt.Settings(1, 6, 1e-4, 1000.0), scenes.sky_cube_direct(8)
+    osc = po.OracleScene(w, h, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), scene.triangles, nodes, scene.triangle_indices, sky, 0)
+    want = np.zeros((h, w, 4), np.float32)
+    for t in range(11, 23):
+        want = osc.render(t, want)[0]
+    for flag in (pt.PT_FLAG_POOL_KERNEL, pt.PT_FLAG_TILE_KERNEL):
+        got, _, stats = _render(pt, scene, w, h, st, sky, flag, 12)
+        assert stats["guard_nodes"] == 0 and stats["guarded"] == 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the same mesh with its own tree does get one
+    assert _render(pt, scenes.bunny(n=32), w, h, st, sky, pt.PT_FLAG_POOL_KERNEL, 2)[2]["guard_nodes"] > 0

@@ -332,6 +332,30 @@ def _check_tree(pt, tris, nodes, idx, max_leaf):
     assert seen.all() and visited == len(nodes)
 
 
+def test_padded_sah_builder_leaves_every_triangle_its_room(pt, po, scenes):
+    """pt_bvh_build_sah_padded (the tree the megakernels walk by default): the invariants of the plain builder, every
+    leaf's box at least pad[t] around each of its triangles on every side, and -- traversed by the oracle's hitScene --
+    the same picture as the reference tree (a padded tree only ever tests more)."""
+    rng = np.random.default_rng(4)
+    tris = scenes.blob_mesh(12)
+    pad = rng.uniform(0.0, 0.02, len(tris)).astype(np.float32)
+    pad[::7] = 0.0
+    nodes, idx = pt.bvh_build_sah(tris, pad=pad)
+    _check_tree(pt, tris, nodes, idx, 4)
+    lo = np.minimum(np.minimum(tris["a"], tris["b"]), tris["c"])
+    hi = np.maximum(np.maximum(tris["a"], tris["b"]), tris["c"])
+    for nd in nodes[nodes["count"] > 0]:
+        t = idx[int(nd["left"]):int(nd["left"]) + int(nd["count"])]
+        assert (lo[t] - pad[t, None] >= nd["min"]).all() and (hi[t] + pad[t, None] <= nd["max"]).all()
+    assert pt.lib().pt_bvh_build_sah_padded(tris.ctypes.data, len(tris), None, None, None) == -1
+    scene = scenes.bunny(n=12)
+    st = pt.Settings(1, 5, 1e-4, 1000.0)
+    ref = po.from_scene(scene, 96, 54, st, None).render(3)[0]
+    padded = po.OracleScene(96, 54, scene.camera.buffer(), st.buffer(), po.pack_spheres(scene.spheres), scene.triangles,
+                            *pt.bvh_build_sah(scene.triangles, pad=np.full(len(scene.triangles), 3e-3, np.float32)), None, 0).render(3)[0]
+    assert np.array_equal(ref.view(np.uint32), padded.view(np.uint32))
+
+
 def test_sah_builder_invariants_and_same_hits_as_the_reference_tree(pt, po, scenes):
     """pt_bvh_build_sah (what PT_FLAG_REBUILD_BVH walks): a valid tree in the reference's node format over the same
     triangles, with fewer traversal steps, and -- traversed by the oracle's hitScene -- the same closest hits as the
