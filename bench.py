@@ -56,10 +56,14 @@ def algorithmic_bytes(st: dict, pixel_frames: int) -> float:
             + 32.0 * pixel_frames)
 
 
-def working_set_bytes(scene) -> int:
+def working_set_bytes(scene, second_tree_nodes: int = 0) -> int:
     """What a BVH walk reads, as the library stores it: 32 B per node and 64 B per triangle in the walk table, 48 B of
-    vertex normals per triangle."""
-    return 32 * int(len(scene.nodes)) + (64 + 48) * int(len(scene.triangles))
+    vertex normals per triangle; with the library's second tree the same again for its nodes and its own order of the
+    triangles, plus its four-child records (64 B each, about one per three nodes)."""
+    one = 32 * int(len(scene.nodes)) + (64 + 48) * int(len(scene.triangles))
+    if second_tree_nodes:
+        one += 32 * second_tree_nodes + (64 + 48) * int(len(scene.triangles)) + 64 * (second_tree_nodes // 3)
+    return one
 
 
 def sky_loop_pixels(flags, w: int, h: int) -> int:
@@ -329,7 +333,7 @@ def main():
         # fraction of the FP32 vector peak (the metric's own).  The traffic counter (TCC read/write requests to the fabric)
         # then tallies cache-served misses too, so its rate is reported as `fabric_frac`, not as a fraction of an HBM roof.
         # Only a working set beyond that cache (the 10 M-triangle field) makes the counter an HBM figure and HBM the bound.
-        ws = working_set_bytes(scene)
+        ws = working_set_bytes(scene, timed_stats["guard_nodes"])
         hbm_bound = ws > INFINITY_CACHE_BYTES
         if hbm_bound and fabric_frac is not None:
             roof = {"bound": "hbm", "achieved": fabric_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric_frac,
