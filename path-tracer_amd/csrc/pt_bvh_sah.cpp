@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ptrt.h"
@@ -119,56 +121,137 @@ struct SahBuilder {
         return found;
     }
 
-    uint32_t build(uint32_t n_tris)
+    // Splits the node `nd` (a leaf over idx[first .. first+count)) if the heuristic says so: partitions its range of idx in
+    // place and fills the two children.  False: it stays a leaf.
+    bool split(const PtNode &nd, PtNode &left, PtNode &right)
     {
-        struct Todo { uint32_t node; };
+        const uint32_t first = nd.left_child_index, count = nd.triangle_count;
+        if (count <= 1) return false;
         Box b, cb;
-        node_bounds(0, n_tris, b, cb);
-        auto put = [&](uint32_t ni, const Box &bb, uint32_t first, uint32_t count) {
-            PtNode &n = nodes[ni];
-            for (int a = 0; a < 3; a++) { n.min_corner[a] = bb.mn[a]; n.max_corner[a] = bb.mx[a]; }
-            n.left_child_index = first;
-            n.triangle_count = count;
-        };
-        put(0, b, 0, n_tris);
-        used = 1;
-        std::vector<uint32_t> todo{0};
+        node_bounds(first, count, b, cb);
+        int axis = 0, bin = 0;
+        float cost = 0.0f;
+        uint32_t mid;
+        const bool have = best_split(first, count, b, cb, axis, bin, cost);
+        if (have && (count > kMaxLeaf || cost < (float)count)) {
+            const float lo = cb.mn[axis], scale = (float)kBins / (cb.mx[axis] - cb.mn[axis]);
+            uint32_t *begin = idx + first, *end = begin + count;
+            uint32_t *m = std::partition(begin, end, [&](uint32_t t) {
+                int k = (int)((cen[3 * (size_t)t + axis] - lo) * scale);
+                k = std::min(std::max(k, 0), kBins - 1);
+                return k < bin;
+            });
+            mid = (uint32_t)(m - begin);
+        } else if (count > kMaxLeaf) {
+            mid = count / 2;  // all centroids in one place: halve by index, so that no leaf outgrows the device's inline leaves
+        } else {
+            return false;  // a leaf
+        }
+        if (mid == 0 || mid == count) return false;
+        Box lb, rb, dummy;
+        node_bounds(first, mid, lb, dummy);
+        node_bounds(first + mid, count - mid, rb, dummy);
+        put(left, lb, first, mid);
+        put(right, rb, first + mid, count - mid);
+        return true;
+    }
+    static void put(PtNode &n, const Box &bb, uint32_t first, uint32_t count)
+    {
+        for (int a = 0; a < 3; a++) { n.min_corner[a] = bb.mn[a]; n.max_corner[a] = bb.mx[a]; }
+        n.left_child_index = first;
+        n.triangle_count = count;
+    }
+
+    // The subtree below out[root] (a leaf over its range), depth first, children appended to `out` (numbers local to it).
+    void build_below(std::vector<PtNode> &out, uint32_t root)
+    {
+        std::vector<uint32_t> todo{root};
         while (!todo.empty()) {
             const uint32_t ni = todo.back();
             todo.pop_back();
-            const uint32_t first = nodes[ni].left_child_index, count = nodes[ni].triangle_count;
-            if (count <= 1) continue;
-            node_bounds(first, count, b, cb);
-            int axis = 0, bin = 0;
-            float cost = 0.0f;
-            uint32_t mid;
-            const bool have = best_split(first, count, b, cb, axis, bin, cost);
-            if (have && (count > kMaxLeaf || cost < (float)count)) {
-                const float lo = cb.mn[axis], scale = (float)kBins / (cb.mx[axis] - cb.mn[axis]);
-                uint32_t *begin = idx + first, *end = begin + count;
-                uint32_t *m = std::partition(begin, end, [&](uint32_t t) {
-                    int k = (int)((cen[3 * (size_t)t + axis] - lo) * scale);
-                    k = std::min(std::max(k, 0), kBins - 1);
-                    return k < bin;
-                });
-                mid = (uint32_t)(m - begin);
-            } else if (count > kMaxLeaf) {
-                mid = count / 2;  // all centroids in one place: halve by index, so that no leaf outgrows the device's inline leaves
-            } else {
-                continue;  // a leaf
-            }
-            if (mid == 0 || mid == count) continue;
-            Box lb, rb, dummy;
-            node_bounds(first, mid, lb, dummy);
-            node_bounds(first + mid, count - mid, rb, dummy);
-            const uint32_t li = used;
-            used += 2;
-            put(li, lb, first, mid);
-            put(li + 1, rb, first + mid, count - mid);
-            nodes[ni].left_child_index = li;
-            nodes[ni].triangle_count = 0;
+            PtNode l, r;
+            if (!split(out[ni], l, r)) continue;
+            const uint32_t li = (uint32_t)out.size();
+            out.push_back(l);
+            out.push_back(r);
+            out[ni].left_child_index = li;
+            out[ni].triangle_count = 0;
             todo.push_back(li + 1);  // (left subtree first, like the reference's recursion: parents before children)
             todo.push_back(li);
+        }
+    }
+
+    // The whole tree into `nodes`.  Large inputs: the top of the tree level by level on this thread until there are
+    // enough subtrees, those by `n_threads` workers into arrays of their own (every subtree owns its range of idx), then
+    // appended in the order the top produced them -- the same tree whatever the number of threads.
+    uint32_t build(uint32_t n_tris, unsigned n_threads)
+    {
+        Box b, cb;
+        node_bounds(0, n_tris, b, cb);
+        std::vector<PtNode> top(1);
+        put(top[0], b, 0, n_tris);
+        std::vector<uint32_t> open{0};  // leaves of the top that may still be split
+        const bool big = n_tris >= 65536, parallel = big && n_threads > 1;
+        if (big) {  // (whatever the number of threads: the numbering of the nodes must not depend on it)
+            const size_t want = 128;
+            while (!open.empty() && open.size() < want) {
+                std::vector<uint32_t> next;
+                bool any = false;
+                for (uint32_t ni : open) {
+                    PtNode l, r;
+                    if (top[ni].triangle_count < 4096u || !split(top[ni], l, r)) { next.push_back(ni); continue; }
+                    const uint32_t li = (uint32_t)top.size();
+                    top.push_back(l);
+                    top.push_back(r);
+                    top[ni].left_child_index = li;
+                    top[ni].triangle_count = 0;
+                    next.push_back(li);
+                    next.push_back(li + 1);
+                    any = true;
+                }
+                open.swap(next);
+                if (!any) break;
+            }
+        }
+        std::vector<std::vector<PtNode>> sub(open.size());
+        auto work = [&](size_t k) {
+            sub[k].push_back(top[open[k]]);
+            build_below(sub[k], 0);
+        };
+        if (parallel) {
+            std::atomic<size_t> next_job{0};
+            std::atomic<bool> failed{false};
+            std::vector<std::thread> pool;
+            auto loop = [&]() {
+                try {
+                    for (size_t k; (k = next_job.fetch_add(1)) < sub.size();) work(k);
+                } catch (...) {
+                    failed = true;
+                }
+            };
+            for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(loop);
+            loop();
+            for (std::thread &t : pool) t.join();
+            if (failed) throw std::bad_alloc();
+        } else {
+            for (size_t k = 0; k < sub.size(); k++) work(k);
+        }
+        // the top as it is, every subtree's descendants behind it (its root already has a place in the top)
+        used = (uint32_t)top.size();
+        std::copy(top.begin(), top.end(), nodes);
+        for (size_t k = 0; k < sub.size(); k++) {
+            const std::vector<PtNode> &sv = sub[k];
+            if (sv.size() == 1) continue;  // stayed a leaf
+            const uint32_t base = used - 1u;  // local number j >= 1 becomes base + j
+            PtNode root = sv[0];
+            root.left_child_index += base;
+            nodes[open[k]] = root;
+            for (size_t j = 1; j < sv.size(); j++) {
+                PtNode n = sv[j];
+                if (n.triangle_count == 0) n.left_child_index += base;
+                nodes[base + j] = n;
+            }
+            used += (uint32_t)sv.size() - 1u;
         }
         return used;
     }
@@ -210,7 +293,9 @@ static int64_t build_sah_tree(const char *who, const void *tris_v, uint32_t n_tr
                 }
             }
         }
-        const uint32_t used = sb.build(n_tris);
+        unsigned n_threads = std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+        if (const char *env = std::getenv("PTRT_BUILD_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(env));
+        const uint32_t used = sb.build(n_tris, n_threads);
         const size_t cap = (size_t)n_tris * 2u - 1u;
         for (size_t k = used; k < cap; k++) {
             PtNode &n = sb.nodes[k];

@@ -356,6 +356,22 @@ def test_padded_sah_builder_leaves_every_triangle_its_room(pt, po, scenes):
     assert np.array_equal(ref.view(np.uint32), padded.view(np.uint32))
 
 
+def test_sah_builder_is_the_same_for_any_number_of_threads(pt, scenes, monkeypatch):
+    """From 65 536 triangles on the builder splits the top of the tree on the calling thread and hands the subtrees to
+    workers; nodes and permutation must not depend on how many there are."""
+    tris = scenes.blob_mesh(76)
+    assert len(tris) >= 65536
+    pad = np.linspace(0.0, 1e-3, len(tris)).astype(np.float32)
+    trees = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("PTRT_BUILD_THREADS", threads)
+        trees.append(pt.bvh_build_sah(tris) + pt.bvh_build_sah(tris, pad=pad))
+    for other in trees[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(trees[0], other))
+    _check_tree(pt, tris, trees[0][0], trees[0][1], 4)
+    _check_tree(pt, tris, trees[0][2], trees[0][3], 4)
+
+
 def test_sah_builder_invariants_and_same_hits_as_the_reference_tree(pt, po, scenes):
     """pt_bvh_build_sah (what PT_FLAG_REBUILD_BVH walks): a valid tree in the reference's node format over the same
     triangles, with fewer traversal steps, and -- traversed by the oracle's hitScene -- the same closest hits as the
