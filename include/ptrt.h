@@ -77,7 +77,8 @@ typedef enum pt_status {
  * cannot lose a hit, and every triangle hit found on it is checked to be the one a walk of the caller's tree returns;
  * a ray that fails the check, or starts too far from the mesh, walks the caller's tree.  Results are bit for bit the
  * same either way (the per-tile kernel, pt_trace_rays and PT_FLAG_DETAILED_STATS always walk the caller's tree); the
- * flag is there to measure the difference and to save the second tree's memory (about as much again as the first). */
+ * flag is there to measure the difference and to save the second tree's memory (about as much again as the first): set
+ * before pt_set_mesh it keeps the tree from being built, set afterwards it only keeps rays off it. */
 #define PT_FLAG_REFERENCE_WALK 256u
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */

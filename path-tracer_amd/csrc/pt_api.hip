@@ -298,13 +298,13 @@ PtDeviceScene device_scene(const pt_ctx *ctx)
     sc.tri_materials = (ctx->flags & PT_FLAG_TRIANGLE_MATERIALS) ? 1u : 0u;
     sc.t_min = ctx->settings.t_min;
     sc.t_max = ctx->settings.t_max;
-    sc.guard_on = ctx->guard_on ? 1u : 0u;
+    sc.guard_on = (ctx->guard_on && !(ctx->flags & PT_FLAG_REFERENCE_WALK)) ? 1u : 0u;  // (the flag also works on a mesh that has the tree)
     for (int k = 0; k < 3; k++) sc.guard_center[k] = ctx->guard_center[k];
     sc.guard_radius = ctx->guard_radius;
     sc.guard_reach = ctx->guard_reach;
     sc.guard_margin = ctx->guard_margin;
     sc.guard_root = ctx->guard_root;
-    sc.guard_quads = ctx->guard_quads;
+    sc.guard_quads = sc.guard_on ? ctx->guard_quads : 0u;
     return sc;
 }
 

@@ -231,3 +231,24 @@ def test_callers_tree_with_boxes_that_do_not_contain_their_triangles(pt, po, sce
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     # the same mesh with its own tree does get one
     assert _render(pt, scenes.bunny(n=32), w, h, st, sky, pt.PT_FLAG_POOL_KERNEL, 2)[2]["guard_nodes"] > 0
+
+
+def test_flag_set_after_the_mesh_keeps_rays_off_the_second_tree(pt, scenes):
+    scene, sky, st = scenes.bunny(n=32), scenes.sky_cube_direct(8), pt.Settings(1, 5, 1e-4, 1000.0)
+    for kernel in (pt.PT_FLAG_POOL_KERNEL, pt.PT_FLAG_TILE_KERNEL):
+        r = pt.Renderer(scene, 128, 72, settings=st, flags=kernel)
+        r.set_sky_cube(sky)
+        r.render_frames(5, 1, 12)
+        with_tree, s1 = r.read_sum().copy(), r.stats()
+        assert s1["guard_nodes"] > 0 and s1["guarded"] > 0
+        r.set_flags(kernel | pt.PT_FLAG_REFERENCE_WALK)
+        r.reset_ready_samples()
+        r.render_frames(5, 1, 12)
+        s2 = r.stats()   # (the counters start over with the reset)
+        assert s2["guarded"] == 0 and s2["rays"] == s1["rays"], "no ray walked the second tree while the flag was set"
+        assert np.array_equal(r.read_sum().view(np.uint32), with_tree.view(np.uint32))
+        r.set_flags(kernel)
+        r.reset_ready_samples()
+        r.render_frames(5, 1, 12)
+        assert r.stats()["guarded"] == s1["guarded"] and np.array_equal(r.read_sum().view(np.uint32), with_tree.view(np.uint32))
+        r.close()
