@@ -1,3 +1,7 @@
+#!/bin/bash
+# GPU box: one bench line for each of the other configurations (the reference-shaped single dispatch at depth 8 and 32,
+# the 4K / 4096-frame mesh scene, the sphere-only scene, the Cornell box) and the short-launch table, into
+# gpurun_out/r03_final/.  Usage: bash tools/bench_other_configs.sh
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_final; mkdir -p $O
