@@ -155,7 +155,7 @@ int pt_render(pt_ctx *ctx, uint32_t time);
  * n_frames pt_render calls (every frame is summed on its own and the frames are added in order).
  * Launches of 16 frames or more are split into work items of several frames by measured cost
  * and summed per item: same samples, sums equal up to fp32 summation order, and several times
- * the throughput (1080p bench scene: 0.52 ms for one frame, 0.16 ms per frame in a 15-frame
+ * the throughput (1080p bench scene: 0.50 ms for one frame, 0.16 ms per frame in a 15-frame
  * launch, 0.09 ms in a 16-frame one, 0.05 ms from 256 frames on). */
 int pt_render_frames(pt_ctx *ctx, uint32_t time0, uint32_t stride, uint32_t n_frames);
 /* Device memory pt_render_frames allocates on demand and keeps until pt_destroy (it never shrinks): the work-item

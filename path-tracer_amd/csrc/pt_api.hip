@@ -54,7 +54,7 @@ struct pt_ctx {
     float4 *tri_nrm = nullptr;
     uint32_t n_nodes = 0, root_token = 0, bvh_depth = 0, tri_base = 0;
     float4 root_pair[4] = {};
-    uint32_t walk_depth = 0;  // deepest leaf of any tree in the walk table (the traversal stacks' bound)
+    uint32_t walk_depth = 0;  // deeper of the caller's tree and the second tree's pair form (the pooled kernel's stack bound)
     // the guard tree (PtDeviceScene::guard_on ...), if pt_set_mesh built one
     bool guard_on = false;
     float guard_center[3] = {}, guard_radius = 0.0f, guard_reach = 0.0f, guard_margin = 0.0f;
@@ -791,7 +791,7 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
                     }
             }
             quad_first_unit = table_units;  // (even)
-            if (quad_first_unit + 2 * (uint64_t)quad_nodes.size() > (1ull << 27) || 3u * (q_depth + 1u) + 1u > PT_MAX_BVH_DEPTH) quad_nodes.clear();  // no room: the pair form alone
+            if (quad_first_unit + 2 * (uint64_t)quad_nodes.size() > (1ull << 27)) quad_nodes.clear();  // no room: the pair form alone
             else table_units = quad_first_unit + 2 * (uint64_t)quad_nodes.size();
         }
     }
@@ -909,8 +909,9 @@ static int pt_set_mesh_impl(pt_ctx *ctx, const void *tris_v, uint32_t n_tris, co
     if (nodes[0].triangle_count == 0)
         for (int k = 0; k < 4; k++) ctx->root_pair[k] = h_nodes[2 * ((size_t)nodes[0].left_child_index + 1) + k];
     ctx->bvh_depth = max_depth;
-    // (a walk of the four-child form pushes up to three entries per level)
-    ctx->walk_depth = std::max(max_depth, gp.on ? std::max(g_depth, quad_nodes.empty() ? 0u : 3u * (q_depth + 1u) + 1u) : 0u);
+    // (the pooled kernel walks the second tree's pair form; the four-child form, which the other kernels walk, gives a
+    // walk up rather than outgrow the stack it finds, so those stay sized by the caller's tree)
+    ctx->walk_depth = std::max(max_depth, gp.on ? g_depth : 0u);
     ctx->guard_on = gp.on;
     if (gp.on) {
         for (int k = 0; k < 3; k++) ctx->guard_center[k] = gp.center[k];
@@ -1207,11 +1208,11 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
         p.n_frames = 1;
         p.accum = ctx->window_frame;
         p.gstack_cap = 0;
-        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->n_tiles, ctx->walk_depth);
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(ctx->n_tiles, ctx->bvh_depth);
         if (gs) {
             int rc = ensure_gstack(ctx, gs);
             if (rc != PT_OK) return rc;
-            p.gstack_cap = ctx->walk_depth;
+            p.gstack_cap = ctx->bvh_depth;
             p.gstack_blocks = ctx->n_tiles;
         }
         p.gstack = ctx->gstack;
@@ -1224,7 +1225,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
             ctx->window_shown = std::min(ctx->window_size, ctx->ready_samples);
             ctx->ready_samples = std::min(ctx->ready_samples + 1u, ctx->window_size);
             p.time0 = time0 + f * stride;
-            PT_HIP(ctx, pt_launch_trace(p, ctx->walk_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
+            PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, sch, ctx->stream));
             uint32_t *slot = ctx->window_ring + (size_t)(ctx->window_seq % ctx->window_size) * n_px;
             PT_HIP(ctx, pt_launch_window_push(ctx->window_frame, ctx->accum, slot, n_px, ctx->stream));
             ctx->window_seq++;
@@ -1249,7 +1250,7 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
             // one row of partial sums (and, for deep trees, one set of spilled stacks) per tile and frame: above the
             // limit the frames run one after the other, one item per tile, with no such rows at all
             const uint64_t cap = pt_trace_item_cap(ctx->n_tiles, batch, bs);
-            const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->walk_depth));
+            const uint64_t bytes = cap * (64u * sizeof(float4) + sizeof(uint4)) + (use_pool ? 0 : pt_trace_gstack_bytes((uint32_t)cap, ctx->bvh_depth));
             const uint64_t limit = use_static ? PT_STATIC_SCRATCH_BYTES - static_mark - 4096u : PT_SHORT_LAUNCH_SCRATCH_LIMIT;
             if (bytes > limit) bs.min_planned_frames = regroup_frames;  // frame after frame, one item per tile
         }
@@ -1310,20 +1311,20 @@ static int render_frames_unguarded(pt_ctx *ctx, uint32_t time0, uint32_t stride,
         bs.partial = partial;
         bs.item_cap = item_cap;
         // spill space for traversal stacks deeper than the per-tile kernel keeps in LDS
-        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->walk_depth);
+        const size_t gs = use_pool ? 0 : pt_trace_gstack_bytes(blocks, ctx->bvh_depth);
         p.gstack = ctx->gstack;
         if (gs && use_static) {
             p.gstack = static_cast<uint32_t *>(carve(gs));
             if (!p.gstack)
-                return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space for this launch, beyond what is left of the %llu-byte static scratch", ctx->walk_depth, gs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
+                return fail(ctx, PT_ERR_LIMIT, "pt_render_frames_static: a BVH of depth %u needs %zu bytes of traversal-stack spill space for this launch, beyond what is left of the %llu-byte static scratch", ctx->bvh_depth, gs, (unsigned long long)PT_STATIC_SCRATCH_BYTES);
         } else if (gs) {
             int rc = ensure_gstack(ctx, gs);
             if (rc != PT_OK) return rc;
             p.gstack = ctx->gstack;
         }
-        p.gstack_cap = gs ? ctx->walk_depth : 0;
+        p.gstack_cap = gs ? ctx->bvh_depth : 0;
         p.gstack_blocks = gs ? blocks : 0;
-        PT_HIP(ctx, pt_launch_trace(p, ctx->walk_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
+        PT_HIP(ctx, pt_launch_trace(p, use_pool ? ctx->walk_depth : ctx->bvh_depth, (ctx->flags & PT_FLAG_DETAILED_STATS) != 0, bs, ctx->stream));
         done += batch;
         ctx->frames += batch;
         ctx->paths += (uint64_t)p.cols * p.rows * batch * ctx->settings.samples_per_pixel;
@@ -1559,7 +1560,7 @@ static int pt_trace_rays_impl(pt_ctx *ctx, const float *origins, const float *di
     q.walked = reinterpret_cast<uint32_t *>(cur);
     q.n = n;
     uint32_t *gs_mem = nullptr;
-    const uint32_t depth = ctx->walk_depth;  // (the deeper of the two trees a ray may walk)
+    const uint32_t depth = ctx->bvh_depth;  // (a walk of the second tree's four-child form never needs more stack than it finds)
     const size_t gs = pt_ray_query_gstack_bytes(n, depth);
     hipError_t e = hipSuccess;
     if (gs) e = hipMalloc((void **)&gs_mem, gs);

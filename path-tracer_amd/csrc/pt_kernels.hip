@@ -69,7 +69,8 @@ struct Closest {
 };
 
 #define PT_ID_TIE 0x10000000u
-#define PT_ID_INDEX 0x0FFFFFFFu
+#define PT_ID_ABANDONED 0x08000000u  // a walk of the guard tree's four-child form that ran out of stack: its record says nothing
+#define PT_ID_INDEX 0x07FFFFFFu      // (a table position is below 2^27)
 
 struct HitRecord {
     bool hit;
@@ -375,8 +376,11 @@ __device__ __forceinline__ void walk_enter(WalkU &w)
 // compute.wgsl:441-456 on the box origin + byte * scale up to a rounding that the guard tree's padding covers --, the
 // children sorted by entry distance, the nearest entered and the others pushed farthest first.  Which order the children
 // are visited in is free here: the guard walk only has to reach every box that a hit may lie in.
+// The walk has room for `stack_cap` entries, whatever the tree's depth: a visit that could overflow it gives the walk up
+// (PT_ID_ABANDONED on the record; the caller sends the ray through the reference tree, whose depth the stack IS sized
+// for) -- a visit pushes at most three entries, and walks that come anywhere near a full stack do not occur in practice.
 template <typename StackT>
-__device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 q1, float4 q2, float4 q3, WalkU &w, StackT stack, bool &next_node)
+__device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 q1, float4 q2, float4 q3, WalkU &w, StackT stack, bool &next_node, uint32_t stack_cap)
 {
     const float ax = q0.w * inv.x, ay = q3.z * inv.y, az = q3.w * inv.z;
     const float bx = (q0.x - o.x) * inv.x, by = (q0.y - o.y) * inv.y, bz = (q0.z - o.z) * inv.z;
@@ -408,6 +412,10 @@ __device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 
     order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
     if (dist[0] > w.nearest) {
         next_node = true;
+    } else if (w.sp + 3u > stack_cap) {
+        w.rec.index |= PT_ID_ABANDONED;
+        w.sp = 0;
+        next_node = true;  // (an empty stack: the walk ends here)
     } else {
         w.node = k[0];
         if (dist[3] < w.nearest) stack.push(w.sp++, k[3]);
@@ -416,8 +424,9 @@ __device__ __forceinline__ void walk_quad_visit(v3 o, v3 inv, float4 q0, float4 
     }
 }
 
+// stack_cap: entries the stack has room for (only a walk of the guard tree's four-child form looks at it).
 template <bool STATS, typename StackT>
-__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn)
+__device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &ray, WalkU &w, StackT stack, Counters &cn, uint32_t stack_cap)
 {
     const v3 o = ray.o, d = ray.d;
     const bool tri = w.leaf_left != 0u;
@@ -436,7 +445,7 @@ __device__ __forceinline__ bool walk_step_u(const PtDeviceScene &sc, const Ray &
         // interior-node branch, where they would cost that branch a second wait)
         asm volatile("" : : "v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.x), "v"(q3.y));
         if (!tri && !STATS && sc.guard_quads != 0u && w.node >= sc.guard_quads) {
-            walk_quad_visit(o, w.inv, q0, q1, q2, q3, w, stack, next_node);
+            walk_quad_visit(o, w.inv, q0, q1, q2, q3, w, stack, next_node, stack_cap);
         } else if (!tri) {
             if (STATS) cn.interior++;
             float d1, d2;
@@ -1038,9 +1047,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                 bool path_done = false;
                 v3 result = V3(0.0f, 0.0f, 0.0f);
                 if constexpr (!STATS) {
-                    if (!need_new && on_guard && w.rec.hit && w.rec.is_tri) {
-                        PT_FRESH_PARAMS(L);
-                        redo = (w.rec.index & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(L.sc, cur, w.rec);
+                    if (!need_new && on_guard) {
+                        if ((w.rec.index & PT_ID_ABANDONED) != 0u) {
+                            redo = true;
+                        } else if (w.rec.hit && w.rec.is_tri) {
+                            PT_FRESH_PARAMS(L);
+                            redo = (w.rec.index & PT_ID_TIE) != 0u || !pt_guard_hit_is_certain(L.sc, cur, w.rec);
+                        }
                     }
                 }
                 if (!need_new && !redo) {
@@ -1065,10 +1078,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
                     w.leaf_left = 0;
                     on_guard = false;
                     if constexpr (!STATS) {
-                        if (mode == M_WALK && !redo && L.sc.guard_on != 0u && pt_guard_in_reach(L.sc, cur.o, cur.d)) {
+                        // (this kernel walks the guard tree in its four-child form only: that walk never needs more stack than
+                        // there is, so the stack stays sized by the reference tree)
+                        if (mode == M_WALK && !redo && L.sc.guard_quads != 0u && pt_guard_in_reach(L.sc, cur.o, cur.d)) {
                             on_guard = true;
                             cn.guarded++;
-                            w.node = L.sc.guard_quads != 0u ? L.sc.guard_quads : L.sc.guard_root;
+                            w.node = L.sc.guard_quads;
                             w.sp = 0;
                             if (w.rec.hit) w.nearest = pt_min(9999.0f, w.rec.t);
                         }
@@ -1095,7 +1110,14 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, STATS ? (PT_TRACE_WAVES_PER_EU < 4 
             g_diag_marks[blockIdx.x * 8 + (diag_steps >> 10) - 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (mode == M_WALK) {
-            if (walk_step_u<STATS>(sc, cur, w, stack, cn)) mode = M_SHADE;
+#ifdef PT_TUNING
+            // (tuning builds: PTRT_POOL_START, which this kernel has no other use for, caps the stack that a walk of the four-child
+            // form may use -- the way to exercise its giving up, which real scenes never trigger)
+            const uint32_t stack_cap = min(OVERFLOW ? P.gstack_cap : (uint32_t)PT_LDS_STACK, P.pool_start ? P.pool_start : 0xFFFFFFFFu);
+#else
+            const uint32_t stack_cap = OVERFLOW ? P.gstack_cap : (uint32_t)PT_LDS_STACK;
+#endif
+            if (walk_step_u<STATS>(sc, cur, w, stack, cn, stack_cap)) mode = M_SHADE;
         }
 #ifdef PT_DIAG
         { const unsigned long long t = clock64(); diag_a += t - diag_s; }
@@ -2321,19 +2343,19 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
     // reference tree.  (This is also how that scheme is tested on rays aimed at edges, vertices and grazing angles.)
     Closest c;
     bool settled = false;
-    if (try_guard && Q.sc.guard_on != 0u && pt_guard_in_reach(Q.sc, r.o, r.d)) {
+    if (try_guard && Q.sc.guard_quads != 0u && pt_guard_in_reach(Q.sc, r.o, r.d)) {
         WalkU w;
         w.rec = hit_spheres<false>(Q.sc, r.o, r.d, cn);
         w.nearest = w.rec.hit ? pt_min(9999.0f, w.rec.t) : 9999.0f;
-        w.node = Q.sc.guard_quads != 0u ? Q.sc.guard_quads : Q.sc.guard_root;
+        w.node = Q.sc.guard_quads;
         w.sp = 0;
         w.leaf_left = 0;
         w.top = 0;
         w.inv = pt_rcp3(r.d);
         uint32_t trips = 1;
-        while (!walk_step_u<false>(Q.sc, r, w, stack, cn)) trips++;
+        while (!walk_step_u<false>(Q.sc, r, w, stack, cn, OVERFLOW ? Q.gstack_cap : PT_LDS_STACK)) trips++;
         c = w.rec;
-        settled = !(c.hit && c.is_tri) || ((c.index & PT_ID_TIE) == 0u && pt_guard_hit_is_certain(Q.sc, r, c));
+        settled = (c.index & PT_ID_ABANDONED) == 0u && (!(c.hit && c.is_tri) || ((c.index & PT_ID_TIE) == 0u && pt_guard_hit_is_certain(Q.sc, r, c)));
 #ifdef PT_TUNING
         if (Q.walked) Q.walked[i] = (settled ? 1u : 2u) | (trips << 2);  // (tuning builds: the guard walk's steps ride along)
 #else
