@@ -608,7 +608,7 @@ static void plan_guard(const PtTriangle *tris, uint32_t n_tris, const PtNode *no
     }
     const double u = 5.9604644775390625e-08;  // 2^-24
     const double rb = (radius + edge_max) * 1.000001;
-    const double reach = 8.0 * rb;
+    const double reach = (double)env_u32("PTRT_GUARD_REACH", 8) * rb;  // (the factor: tuning builds only)
     if (!(rb > 0.0) || !(reach < 1e15)) return;
     const double o_max = std::max(std::max(std::fabs(gp.center[0]), std::fabs(gp.center[1])), std::fabs(gp.center[2])) + reach;  // no origin in reach has a larger coordinate
     const double slab = 8.0 * u * (abs_max + reach + o_max) + 6.0 * u * reach + 1e-30;
