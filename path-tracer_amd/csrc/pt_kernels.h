@@ -80,14 +80,15 @@ struct PtDeviceScene {
     uint32_t sky_size;
     uint32_t tri_materials;  // 1: triangles shade with their records' albedo and material (opt-in extension)
     float t_min, t_max;
-    // The guard tree (pooled kernel only; guard_on == 0: none).  A second tree over the same triangles, built by the
-    // library with a surface-area heuristic over triangle bounds padded by more than the triangle test's own rounding
-    // error can move a hit point (for rays within `guard_reach` of the mesh), in the same table behind the reference
-    // tree: its pairs at positions guard_root.. and its triangle records at slots n_idx.. in its own leaf order.  A ray
-    // within reach that has passed the reference root's boxes walks it instead of the reference tree -- it cannot miss a
-    // triangle that the triangle test accepts -- and its closest hit is then checked to be one the reference walk returns too (the hit point strictly inside the
-    // triangle's own bounds, no second triangle at exactly the same t); a ray that fails the check, or is out of reach,
-    // walks the reference tree.
+    // The guard tree (guard_on == 0: none).  A second tree over the same triangles, built by the library with a
+    // surface-area heuristic over triangle bounds padded by more than the triangle test's own rounding error can move a
+    // hit point (for rays within `guard_reach` of the mesh), in the same table behind the reference tree: its pairs at
+    // positions guard_root.. and its triangle records at slots n_idx.. in its own leaf order.  A ray within reach that
+    // has passed the reference root's boxes walks it instead of the reference tree -- it cannot miss a triangle that the
+    // triangle test accepts -- and its closest hit is then checked to be one the reference walk returns too (the hit point
+    // strictly inside the triangle's own bounds, no second triangle at exactly the same t); a ray that fails the check,
+    // or is out of reach, walks the reference tree.  The pooled kernel walks the pair form, the per-tile kernel and ray
+    // queries the four-child form below.
     uint32_t guard_on;
     uint32_t guard_root;     // table position of the pair of the guard root's children (the guard root is always interior)
     // The guard tree once more, four children to a 64-byte record (the kernels that step one ray per lane walk this form:
