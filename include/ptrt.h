@@ -72,13 +72,13 @@ typedef enum pt_status {
  * cases named at pt_bvh_build_sah (none in 2 million primary rays of the 69 k-triangle scene; the converged images agree
  * far below 1e-3 RMSE), for about a third fewer traversal steps.  No counterpart in the reference. */
 #define PT_FLAG_REBUILD_BVH 128u
-/* Off by default: the pooled kernel walks the caller's tree only.  By default pt_set_mesh (for meshes of 128 triangles
- * or more whose triangles are small against the mesh) also builds a tree of its own, laid out so that a walk of it
- * cannot lose a hit, and every triangle hit found on it is checked to be the one a walk of the caller's tree returns;
- * a ray that fails the check, or starts too far from the mesh, walks the caller's tree.  Results are bit for bit the
- * same either way (the per-tile kernel, pt_trace_rays and PT_FLAG_DETAILED_STATS always walk the caller's tree); the
- * flag is there to measure the difference and to save the second tree's memory (about as much again as the first): set
- * before pt_set_mesh it keeps the tree from being built, set afterwards it only keeps rays off it. */
+/* Off by default: every ray walks the caller's tree only.  By default pt_set_mesh (for meshes of 128 triangles or more
+ * whose triangles are small against the mesh) also builds a tree of its own, laid out so that a walk of it cannot lose a
+ * hit, and every triangle hit found on it is checked to be the one a walk of the caller's tree returns; a ray that fails
+ * the check, or starts too far from the mesh, walks the caller's tree.  Both megakernels and pt_trace_rays do this; results
+ * are bit for bit the same either way (PT_FLAG_DETAILED_STATS always walks the caller's tree: its counters are that
+ * walk's).  The flag is there to measure the difference and to save the second tree's memory (about as much again as the
+ * first): set before pt_set_mesh it keeps the tree from being built, set afterwards it only keeps rays off it. */
 #define PT_FLAG_REFERENCE_WALK 256u
 
 /* Primitive ids reported by pt_read_aov / pt_trace_rays */
