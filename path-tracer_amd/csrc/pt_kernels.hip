@@ -2352,7 +2352,7 @@ __global__ __launch_bounds__(PT_BLOCK) void ray_query_kernel(const PtRayQuery Q)
         w.leaf_left = 0;
         w.top = 0;
         w.inv = pt_rcp3(r.d);
-        uint32_t trips = 1;
+        [[maybe_unused]] uint32_t trips = 1;  // (reported by tuning builds)
         while (!walk_step_u<false>(Q.sc, r, w, stack, cn, OVERFLOW ? Q.gstack_cap : PT_LDS_STACK)) trips++;
         c = w.rec;
         settled = (c.index & PT_ID_ABANDONED) == 0u && (!(c.hit && c.is_tri) || ((c.index & PT_ID_TIE) == 0u && pt_guard_hit_is_certain(Q.sc, r, c)));
